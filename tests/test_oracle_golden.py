@@ -1,0 +1,181 @@
+"""Pin the CPU oracle (oracle/cosmogp_oracle.py) against golden vectors produced
+by the real reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, ulp_diff
+from oracle import cosmogp_oracle as orc
+
+
+@pytest.mark.parametrize('n', [8, 64, 256])
+def test_rbf_kernel_1d_bit_exact(n):
+    g = load_golden('k1d_n%d' % n)
+    ng, fl = float(g['nugget']), float(g['floor'])
+    assert ulp_diff(orc.rbf_kernel_1d(g['x'], g['hyp']), g['K_plain']) == 0
+    assert ulp_diff(orc.rbf_kernel_1d(g['x'], g['hyp'], nugget=ng, floor=fl, y_err=g['yerr']),
+                    g['K_noise']) == 0
+    assert ulp_diff(orc.rbf_kernel_1d(g['x'], g['hyp'], new_x=g['xnew']), g['H']) == 0
+    assert ulp_diff(orc.rbf_kernel_1d(g['xnew'], g['hyp'], nugget=ng), g['Kss']) == 0
+    assert g['H'].shape == (len(g['xnew']), n)
+
+
+@pytest.mark.parametrize('n', [8, 64, 200])
+def test_rbf_kernel_2d(n):
+    g = load_golden('k2d_n%d' % n)
+    ng, fl = float(g['nugget']), float(g['floor'])
+    # restated scipy mahalanobis arithmetic: allow 2 ulp (compiler contraction in
+    # the third-party C loop is not under our control); measured 0.
+    assert ulp_diff(orc.rbf_kernel_2d(g['x'], g['hyp']), g['K_plain']) <= 2
+    assert ulp_diff(orc.rbf_kernel_2d(g['x'], g['hyp'], nugget=ng, floor=fl, y_err=g['yerr']),
+                    g['K_noise']) <= 2
+    assert ulp_diff(orc.rbf_kernel_2d(g['x'], g['hyp'], new_x=g['xnew']), g['H']) <= 2
+    assert ulp_diff(orc.rbf_kernel_2d(g['xnew'], g['hyp'], nugget=ng), g['Kss']) <= 2
+    # the reference's train-train branch has no sigma^2
+    assert abs(g['K_plain'][0, 0] - 1.0) < 1e-15 and g['hyp'][0] != 1.0
+
+
+def test_init_rbf():
+    g = load_golden('init_rbf')
+    xs = [g['x1_%d' % i] for i in range(int(g['n1']))]
+    ys = [g['y1_%d' % i] for i in range(int(g['n1']))]
+    np.testing.assert_allclose(orc.init_rbf(xs, ys), g['guess_1d'], rtol=1e-15)
+    Xs = [g['x2_%d' % i] for i in range(int(g['n2']))]
+    Ys = [g['y2_%d' % i] for i in range(int(g['n2']))]
+    np.testing.assert_allclose(orc.init_rbf(Xs, Ys), g['guess_2d'], rtol=1e-15)
+
+
+def test_inverses():
+    g = load_golden('inverse_n96')
+    inv, ld = orc.cholesky_inverse(g['K'], return_logdet=True)
+    np.testing.assert_allclose(inv, g['chol_inv'], rtol=0, atol=1e-12 * np.abs(g['chol_inv']).max())
+    assert abs(ld - float(g['chol_logdet'])) <= 1e-13 * abs(ld)
+    inv, ld = orc.svd_inverse(g['K'], return_logdet=True)
+    np.testing.assert_allclose(inv, g['svd_inv'], rtol=0, atol=1e-11 * np.abs(g['svd_inv']).max())
+    assert abs(ld - float(g['svd_logdet'])) <= 1e-12 * abs(ld)
+    inv, ld = orc.svd_inverse(g['K_singular'], return_logdet=True)
+    assert abs(ld - float(g['svd_logdet_singular'])) <= 1e-9 * abs(ld)
+    assert int(g['chol_raises_on_singular']) == 1
+    with pytest.raises(np.linalg.LinAlgError):
+        orc.cholesky_inverse(g['K_singular'])
+
+
+def test_loglik_1d():
+    g = load_golden('loglik_1d')
+    n = int(g['nobj'])
+    xs, ys, es = ([g['%s_%d' % (k, i)] for i in range(n)] for k in 'xye')
+    y0 = orc.object_means(ys, xs)
+    ll = orc.total_log_likelihood(ys, xs, 'RBF1D', g['hyp'], float(g['nugget']), es, y0, svd_method=False)
+    assert ll.shape == (1,)
+    np.testing.assert_allclose(ll, g['ll3_chol'], rtol=1e-12)
+    ll = orc.total_log_likelihood(ys, xs, 'RBF1D', g['hyp'], float(g['nugget']), es, y0, svd_method=True)
+    np.testing.assert_allclose(ll, g['ll3_svd'], rtol=1e-10)
+    hf = g['hyp_fitnug']
+    ll = orc.total_log_likelihood(ys, xs, 'RBF1D', hf[:-1], hf[-1], es, y0, svd_method=False)
+    np.testing.assert_allclose(ll, g['ll3_fitnug'], rtol=1e-12)
+    y0s = orc.object_means(ys[:1], xs[:1], substract_mean=True)
+    ll = orc.total_log_likelihood(ys[:1], xs[:1], 'RBF1D', g['hyp'], 0., es[:1], y0s, svd_method=False)
+    np.testing.assert_allclose(ll, g['ll1_submean'], rtol=1e-12)
+
+
+def test_loglik_2d():
+    g = load_golden('loglik_2d')
+    ll = orc.total_log_likelihood([g['y']], [g['x']], 'RBF2D', g['hyp'], 0., [g['e']], [0.], svd_method=False)
+    np.testing.assert_allclose(ll, g['ll_chol'], rtol=1e-12)
+    s, L = orc.init_rbf([g['x']], [g['y']])
+    np.testing.assert_allclose([s, L, L, 0.], g['init_hyp'], rtol=1e-15)
+
+
+def test_find_hyperparameters():
+    g = load_golden('fit_1d_n60')
+    hyp, _ = orc.find_hyperparameters([g['y']], [g['x']], 'RBF1D', g['guess'], [g['e']], [0.], svd_method=False)
+    np.testing.assert_allclose(hyp, g['fit_hyp'], rtol=1e-4)
+    hyp, ng = orc.find_hyperparameters([g['y']], [g['x']], 'RBF1D', g['guess'], [g['e']], [0.],
+                                       fit_nugget=True, svd_method=False)
+    np.testing.assert_allclose(hyp, g['fit_hyp_nug'], rtol=1e-3)
+    assert abs(ng - float(g['fit_nugget'])) < 1e-3
+    np.testing.assert_allclose(orc.init_rbf([g['x']], [g['y']]), g['init_guess'], rtol=1e-15)
+
+
+def test_predict_c1_plumbing():
+    g = load_golden('c1_predict_1d_n256')
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], new_binning=g['xnew'],
+                    svd_method=False)
+    np.testing.assert_allclose(r['prediction'][0], g['pred'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r['covariance'][0], g['cov'], rtol=0, atol=1e-12)
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], svd_method=False)
+    np.testing.assert_allclose(r['prediction'][0], g['pred_same'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.diag(r['covariance'][0]), g['cov_diag_same'], rtol=0, atol=1e-12)
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], new_binning=g['xnew'],
+                    svd_method=True)
+    np.testing.assert_allclose(r['prediction'][0], g['pred_svd'], rtol=0, atol=1e-10)
+    ll = orc.total_log_likelihood([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], [0.], svd_method=False)
+    np.testing.assert_allclose(ll, g['loglik'], rtol=1e-12)
+    # solve-based form agrees with the explicit-inverse form
+    K = orc.rbf_kernel_1d(g['x'], g['hyp'], y_err=g['e'])
+    H = orc.rbf_kernel_1d(g['x'], g['hyp'], new_x=g['xnew'])
+    mu, var, llc = orc.fit_predict_cho(K, g['y'], H, np.full(len(g['xnew']), g['hyp'][0] ** 2))
+    np.testing.assert_allclose(mu, g['pred'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(var, np.diag(g['cov']), rtol=0, atol=1e-11)
+    assert abs(llc - g['loglik'][0]) < 1e-11 * abs(llc)
+
+
+def test_predict_with_mean():
+    g = load_golden('predict_mean_1d_n80')
+    kw = dict(new_binning=g['xnew'], svd_method=False)
+    ng = float(g['nugget'])
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], ng, [g['e']], mean_y=g['mean_y'],
+                    mean_xaxis=g['mean_x'], **kw)
+    np.testing.assert_allclose(r['prediction'][0], g['pred'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(r['covariance'][0], g['cov'], rtol=0, atol=1e-11)
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], ng, [g['e']], mean_y=g['mean_y'],
+                    mean_xaxis=g['mean_x'], svd_method=False)
+    np.testing.assert_allclose(r['prediction'][0], g['pred_same'], rtol=0, atol=1e-11)
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], mean_y=g['mean_y'],
+                    mean_xaxis=g['mean_x'], diff=[0.25], **kw)
+    np.testing.assert_allclose(r['prediction'][0], g['pred_diff'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.diag(r['covariance'][0]), g['cov_diag_diff'], rtol=0, atol=1e-11)
+    r = orc.predict([g['y']], [g['x']], 'RBF1D', g['hyp'], 0., [g['e']], substract_mean=True, **kw)
+    np.testing.assert_allclose(r['prediction'][0], g['pred_submean'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(np.diag(r['covariance'][0]), g['cov_diag_submean'], rtol=0, atol=1e-11)
+    y0 = orc.object_means([g['y']], [g['x']], g['mean_y'], g['mean_x'])
+    np.testing.assert_allclose(y0[0], g['y0'], rtol=1e-14)
+
+
+def test_predict_2d():
+    g = load_golden('predict_2d_n150')
+    r = orc.predict([g['y']], [g['x']], 'RBF2D', g['hyp'], float(g['nugget']), [g['e']],
+                    new_binning=g['xnew'], svd_method=False)
+    np.testing.assert_allclose(r['prediction'][0], g['pred'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(r['covariance'][0], g['cov'], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(r['inv_kernel_matrix'][0], g['inv_kernel_matrix'], rtol=0,
+                               atol=1e-11 * np.abs(g['inv_kernel_matrix']).max())
+
+
+def test_predict_nobject():
+    g = load_golden('predict_nobject_1d')
+    n = int(g['nobj'])
+    xs, ys, es = ([g['%s_%d' % (k, i)] for i in range(n)] for k in 'xye')
+    r = orc.predict(ys, xs, 'RBF1D', g['hyp'], 0., es, new_binning=g['xnew'], svd_method=False)
+    for i in range(n):
+        np.testing.assert_allclose(r['prediction'][i], g['pred_%d' % i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(np.diag(r['covariance'][i]), g['covdiag_%d' % i], rtol=0, atol=1e-11)
+    xs, ys, es = ([g['s%s_%d' % (k, i)] for i in range(n)] for k in 'xye')
+    # reference behaviour (stale index): every H is built on the LAST object's grid
+    r = orc.predict(ys, xs, 'RBF1D', g['hyp'], 0., es, svd_method=False, fix_stale_index=False)
+    for i in range(n):
+        np.testing.assert_allclose(r['prediction'][i], g['spred_stale_%d' % i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(np.diag(r['covariance'][i]), g['scovdiag_%d' % i], rtol=0, atol=1e-11)
+    # the last object is unaffected by the quirk
+    r2 = orc.predict(ys, xs, 'RBF1D', g['hyp'], 0., es, svd_method=False, fix_stale_index=True)
+    np.testing.assert_allclose(r2['prediction'][n - 1], g['spred_stale_%d' % (n - 1)], rtol=0, atol=1e-11)
+
+
+def test_pull():
+    g = load_golden('pull_1d_n20')
+    p, res, _ = orc.compute_pull([g['y']], [g['x']], g['hyp'], nugget=float(g['nugget']),
+                                 y_err=[g['e']], svd_method=False)
+    np.testing.assert_allclose(p, g['pull'], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res, g['residual'], rtol=0, atol=1e-10)
+    p, res, _ = orc.compute_pull([g['y']], [g['x']], g['hyp'], nugget=float(g['nugget']),
+                                 y_err=[g['e']], svd_method=False, substract_mean=True)
+    np.testing.assert_allclose(p, g['pull_submean'], rtol=0, atol=1e-10)
