@@ -1,0 +1,259 @@
+"""ctypes binding of libcosmogp_hip.so (include/cosmogp_hip.h).
+
+Thin by design: numpy arrays in, numpy arrays out, status codes turned into the
+exceptions the reference raises (numpy.linalg.LinAlgError for a non positive
+definite matrix, cosmogp/inv_matrix.py:23).  There is NO CPU fallback: if the
+shared library or a GPU is missing every entry point raises HipUnavailable.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcosmogp_hip.so')
+
+MAT_K, MAT_L, MAT_KINV = 0, 1, 2
+
+#: every symbol include/cosmogp_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
+    'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_fit_set_data', 'cgp_fit',
+    'cgp_fit_predict', 'cgp_fit_fetch', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
+    'cgp_selftest_mfma',
+)
+
+
+class HipUnavailable(RuntimeError):
+    """libcosmogp_hip.so or an MI355X is missing; the product path has no CPU fallback."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_i64 = ctypes.c_int64
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Load the shared library (works without a GPU; compute calls then fail loudly)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable('%s not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                 'or `make -C cosmogp_amd/csrc`' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        lib.cgp_version.restype = ctypes.c_int
+        lib.cgp_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        lib.cgp_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        lib.cgp_destroy.argtypes = [vp]
+        lib.cgp_last_error.argtypes = [vp]
+        lib.cgp_last_error.restype = ctypes.c_char_p
+        lib.cgp_synchronize.argtypes = [vp]
+        lib.cgp_rbf.argtypes = [vp, ctypes.c_int, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64]
+        lib.cgp_cholesky_inverse.argtypes = [vp, _dp, _i64, _i64, _dp, _dp]
+        lib.cgp_fit_set_data.argtypes = [vp, ctypes.c_int, _dp, _dp, _i64]
+        lib.cgp_fit.argtypes = [vp, _dp, _dp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp, _dp]
+        lib.cgp_fit_predict.argtypes = [vp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp]
+        lib.cgp_fit_fetch.argtypes = [vp, ctypes.c_int, _dp]
+        lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
+                                      _i64, _dp, ctypes.c_double, _dp, ctypes.POINTER(ctypes.c_int32), _dp, _dp]
+        lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
+        lib.cgp_microbench.argtypes = [vp, _dp, _dp]
+        lib.cgp_selftest_mfma.argtypes = [vp]
+        _lib = lib
+        return lib
+
+
+def device_count():
+    lib = load_library()
+    c = ctypes.c_int(0)
+    lib.cgp_device_count(ctypes.byref(c))
+    return c.value
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError('expected shape %r, got %r' % (shape, a.shape))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Device(object):
+    """One handle = one GPU + one HIP stream + its HBM workspaces.  Not thread safe."""
+
+    def __init__(self, index=None):
+        lib = load_library()
+        if index is None:
+            index = int(os.environ.get('COSMOGP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        n = device_count()
+        if n == 0:
+            raise HipUnavailable('no HIP device visible: cosmogp_amd needs an MI355X (gfx950); '
+                                 'there is no CPU fallback')
+        self.index = index % n
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        st = lib.cgp_create(self.index, ctypes.byref(self._h))
+        if st != 0:
+            raise HipUnavailable('cgp_create(device=%d) failed with status %d' % (self.index, st))
+        self.dim = None
+        self.n = None
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.cgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- status handling ---------------------------------------------------------
+    def _check(self, st, what):
+        if st == 0:
+            return
+        if st > 0:
+            raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite' % st)
+        msg = self._lib.cgp_last_error(self._h)
+        raise HipError('%s failed (status %d): %s' % (what, st, msg.decode() if msg else ''))
+
+    # ---- operator level ------------------------------------------------------------
+    def rbf(self, dim, x, kp, xnew=None, diag=None):
+        x = _f64(x)
+        n = x.shape[0]
+        kp = _f64(kp, (6,))
+        if xnew is None:
+            out = np.empty((n, n))
+            dg = None if diag is None else _f64(diag, (n,))
+            st = self._lib.cgp_rbf(self._h, dim, _ptr(x), n, None, 0, _ptr(kp), _ptr(dg), _ptr(out), n)
+        else:
+            xnew = _f64(xnew)
+            m = xnew.shape[0]
+            out = np.empty((m, n))
+            st = self._lib.cgp_rbf(self._h, dim, _ptr(x), n, _ptr(xnew), m, _ptr(kp), None, _ptr(out), n)
+        self._check(st, 'cgp_rbf')
+        return out
+
+    def cholesky_inverse(self, K):
+        K = _f64(K)
+        n = K.shape[0]
+        if K.ndim != 2 or K.shape[1] != n:
+            raise ValueError('expected a square matrix')
+        inv = np.empty((n, n))
+        ld = ctypes.c_double(0.)
+        st = self._lib.cgp_cholesky_inverse(self._h, _ptr(K), n, n, _ptr(inv), ctypes.byref(ld))
+        self._check(st, 'cgp_cholesky_inverse')
+        return inv, ld.value
+
+    # ---- fused level ---------------------------------------------------------------
+    def set_data(self, dim, x, resid):
+        x = _f64(x)
+        n = x.shape[0]
+        resid = _f64(resid, (n,))
+        self._check(self._lib.cgp_fit_set_data(self._h, dim, _ptr(x), _ptr(resid), n), 'cgp_fit_set_data')
+        self.dim, self.n = dim, n
+
+    def fit(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., want_var=True):
+        """Returns (loglik, logdet, mu, var); mu/var None when xnew is None."""
+        kp = _f64(kp, (6,))
+        dg = None if diag is None else _f64(diag, (self.n,))
+        ll, ld = ctypes.c_double(0.), ctypes.c_double(0.)
+        if xnew is None:
+            st = self._lib.cgp_fit(self._h, _ptr(kp), _ptr(dg), None, 0, None, float(kss_noise),
+                                   ctypes.byref(ll), ctypes.byref(ld), None, None)
+            self._check(st, 'cgp_fit')
+            return ll.value, ld.value, None, None
+        xnew = _f64(xnew)
+        m = xnew.shape[0]
+        mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
+        mu = np.empty(m)
+        var = np.empty(m) if want_var else None
+        st = self._lib.cgp_fit(self._h, _ptr(kp), _ptr(dg), _ptr(xnew), m, _ptr(mn), float(kss_noise),
+                               ctypes.byref(ll), ctypes.byref(ld), _ptr(mu), _ptr(var))
+        self._check(st, 'cgp_fit')
+        return ll.value, ld.value, mu, var
+
+    def predict(self, xnew, mean_new=None, kss_noise=0., want_cov=False):
+        xnew = _f64(xnew)
+        m = xnew.shape[0]
+        mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
+        mu, var = np.empty(m), np.empty(m)
+        cov = np.empty((m, m)) if want_cov else None
+        st = self._lib.cgp_fit_predict(self._h, _ptr(xnew), m, _ptr(mn), float(kss_noise), _ptr(mu), _ptr(var),
+                                       _ptr(cov))
+        self._check(st, 'cgp_fit_predict')
+        return mu, var, cov
+
+    def fetch(self, which):
+        out = np.empty((self.n, self.n))
+        self._check(self._lib.cgp_fit_fetch(self._h, which, _ptr(out)), 'cgp_fit_fetch')
+        return out
+
+    # ---- batched -------------------------------------------------------------------
+    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.):
+        """xs / resids / diags: lists of per-object arrays (ragged allowed).
+        Returns (loglik[B], info[B], mu[B,m] or None, var[B,m] or None)."""
+        B = len(xs)
+        ns = np.array([len(r) for r in resids], dtype=np.int64)
+        x = _f64(np.concatenate([np.asarray(a, dtype=np.float64).reshape(len(a), -1) for a in xs]).ravel())
+        r = _f64(np.concatenate(resids))
+        d = None if diags is None else _f64(np.concatenate(diags))
+        kp = _f64(kp, (6,))
+        ll = np.empty(B)
+        info = np.zeros(B, dtype=np.int32)
+        if xnew is None:
+            m, xn, mu, var, mn = 0, None, None, None, None
+        else:
+            xn = _f64(xnew)
+            m = xn.shape[0]
+            mu, var = np.empty((B, m)), np.empty((B, m))
+            mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
+        st = self._lib.cgp_batch_fit(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
+                                     _ptr(d), _ptr(kp), _ptr(xn), m, _ptr(mn), float(kss_noise), _ptr(ll),
+                                     info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(mu), _ptr(var))
+        self._check(st, 'cgp_batch_fit')
+        return ll, info, mu, var
+
+    # ---- measurement ---------------------------------------------------------------
+    def bench_fit(self, iters, stages=True):
+        ms = ctypes.c_double(0.)
+        st8 = np.zeros(8) if stages else None
+        self._check(self._lib.cgp_bench_fit(self._h, int(iters), ctypes.byref(ms), _ptr(st8)), 'cgp_bench_fit')
+        return ms.value, st8
+
+    def microbench(self):
+        a, b = ctypes.c_double(0.), ctypes.c_double(0.)
+        self._check(self._lib.cgp_microbench(self._h, ctypes.byref(a), ctypes.byref(b)), 'cgp_microbench')
+        return a.value, b.value
+
+    def selftest_mfma(self):
+        st = self._lib.cgp_selftest_mfma(self._h)
+        if st != 0:
+            msg = self._lib.cgp_last_error(self._h)
+            raise HipError('MFMA self-test failed (%d): %s' % (st, msg.decode() if msg else ''))
+        return True
+
+
+_default = {}
+
+
+def default_device():
+    """Process-wide handle on COSMOGP_DEVICE / LOCAL_RANK (created lazily)."""
+    key = os.getpid()
+    if key not in _default:
+        _default.clear()
+        _default[key] = Device()
+    return _default[key]

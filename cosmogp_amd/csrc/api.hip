@@ -1,0 +1,820 @@
+// libcosmogp_hip: C ABI (include/cosmogp_hip.h) and host-side orchestration of the
+// blocked Cholesky.  gfx950 only.  No torch, no BLAS: every kernel is in kernels.hpp.
+#include "kernels.hpp"
+#include "../../include/cosmogp_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int NB = CGP_NB;
+constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 4) * sizeof(double);
+
+inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// One (possibly batched) problem resident in HBM.
+struct Prob {
+    int B = 1, dim = 1;
+    long n = 0;          // single problem: n; batched: max n
+    long Np = 0, R = 0;  // padded size, total rows (Np + tall rows)
+    long sM = 0;         // batch stride of the matrix buffer (doubles)
+    double* M = nullptr;
+    double* x = nullptr;      long sx = 0;
+    double* r = nullptr;      long sr = 0;
+    double* diag = nullptr;   long sd = 0;
+    double* xnew = nullptr;   long sxn = 0;   // 0 = shared grid
+    double* z = nullptr;                       // solved residual rows, stride Np
+    double* wsW = nullptr;    long sW = 0;
+    double* ldp = nullptr;    long sLd = 0;
+    int* info = nullptr;
+    int* ns = nullptr;
+    double* mean = nullptr;   // shared, may be null
+    double* mu = nullptr; double* var = nullptr; long sOut = 0;
+    double* scal = nullptr;   // [B][2] loglik, logdet
+};
+
+enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_COUNT };
+
+}  // namespace
+
+struct cgp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // single-object state
+    Prob P;
+    bool have_data = false, factored = false;
+    long last_m = 0;
+    bool last_has_mean = false;
+    double last_kss_noise = 0.;
+    DevBuf bM, bx, br, bdiag, bxnew, bz, bws, bldp, binfo, bns, bmean, bmu, bvar, bscal, bkp;
+    DevBuf bC, bout, bns2, bdiag2;            // scratch: square outputs
+    DevBuf box, boxn, bzero;                  // operator-level scratch
+    // batched state
+    Prob Q;
+    DevBuf qM, qx, qr, qdiag, qxnew, qz, qws, qldp, qinfo, qns, qmean, qmu, qvar, qscal;
+    // stage timing
+    bool profiling = false;
+    struct Rec { hipEvent_t a, b; int stage; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double gemm_flops = 0.;
+    long gemm_launches = 0;
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return CGP_E_HIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+#define CHK(expr)                     \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ < 0) return s_;        \
+    } while (0)
+
+int fail(cgp_handle* h, int code, const char* msg) {
+    h->err = msg;
+    return code;
+}
+
+int ensure(cgp_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return 0;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+// grow keeping the first `keep` bytes (device to device)
+int ensure_keep(cgp_handle* h, DevBuf& b, size_t bytes, size_t keep) {
+    if (bytes <= b.cap && b.p) return 0;
+    void* np = nullptr;
+    HIPCHK(hipMalloc(&np, bytes));
+    if (b.p && keep) HIPCHK(hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = np;
+    b.cap = bytes;
+    return 0;
+}
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+struct StageScope {
+    cgp_handle* h;
+    int idx = -1;
+    StageScope(cgp_handle* h_, int stage) : h(h_) {
+        if (!h->profiling) return;
+        cgp_handle::Rec r;
+        auto get = [&]() {
+            if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+            hipEvent_t e; (void)hipEventCreate(&e); return e;
+        };
+        r.a = get(); r.b = get(); r.stage = stage;
+        (void)hipEventRecord(r.a, h->stream);
+        h->recs.push_back(r);
+        idx = (int)h->recs.size() - 1;
+    }
+    ~StageScope() {
+        if (idx >= 0) (void)hipEventRecord(h->recs[idx].b, h->stream);
+    }
+};
+
+int leaf_attr_once(cgp_handle* h) {
+    static bool done = false;
+    if (done) return 0;
+    HIPCHK(hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    done = true;
+    return 0;
+}
+
+// C[rows x cols] = beta C + alpha A B^T ; rows/cols multiples of 128.  tri: rows [0, cols) of
+// the region are lower-triangular (tile granularity), the rest full.
+int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
+                long ld, long sAB, long rows, long cols, long K, bool tri, double alpha, double beta) {
+    if (rows <= 0 || cols <= 0 || K <= 0) return 0;
+    StageScope sc(h, ST_GEMM);
+    long nr = rows / 128, nc = cols / 128;
+    long tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
+    h->gemm_launches++;
+    {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
+        const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
+        h->gemm_flops += 2.0 * K * elems * B;
+    }
+    if (tiles * B >= 192) {
+        dim3 g((unsigned)tiles, 1, (unsigned)B);
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2>), g, dim3(256), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta);
+    } else {
+        nr = rows / 64; nc = cols / 64;
+        tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
+        dim3 g((unsigned)tiles, 1, (unsigned)B);
+        hipLaunchKernelGGL((k_gemm_nt<64, 64, 2, 2>), g, dim3(256), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Recursive blocked Cholesky on columns [c0, c1) of P.M.
+//   chol = true : factor; all rows below (down to P.R, i.e. the tall rows too) are solved/updated
+//   chol = false: L already there; only rows [rlo, R) are solved (W = H L^-T)
+// Every update is one GEMM with the full depth of the finished half, so C traffic is
+// O(N^2 log N) instead of O(N^3 / NB).
+int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, bool chol) {
+    const long ld = P.Np;
+    if (c1 - c0 == NB) {
+        const int blk = (int)(c0 / NB);
+        if (chol) {
+            StageScope sc(h, ST_POTRF);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, P.B), dim3(256), LEAF_LDS, h->stream, P.M, ld, P.sM, (int)c0,
+                               P.wsW, P.sW, P.ldp, P.sLd, P.info, blk);
+            HIPCHK(hipGetLastError());
+        }
+        const long r0 = chol ? c0 + NB : rlo;
+        if (R > r0) {
+            StageScope sc(h, ST_TRSM);
+            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / 64), 1, P.B), dim3(256), LEAF_LDS, h->stream,
+                               P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
+    const long nb = (c1 - c0) / NB;
+    const long mid = c0 + (nb / 2) * NB;
+    CHK(factor_range(h, P, c0, mid, rlo, R, chol));
+    const long rs = chol ? mid : rlo;
+    CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
+                    R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0));
+    return factor_range(h, P, mid, c1, rlo, R, chol);
+}
+
+template <int DIM>
+int launch_assemble_train_t(cgp_handle* h, int B, double* M, long ld, long sM, const double* x, long sx,
+                            const double* diag, long sd, const int* ns, long Np, bool lower_only) {
+    dim3 g((unsigned)(Np / 128), (unsigned)(Np / 64), (unsigned)B);
+    hipLaunchKernelGGL((k_assemble_train<DIM>), g, dim3(256), 0, h->stream, M, ld, sM, x, sx, diag, sd, ns,
+                       (const KParams*)h->bkp.p, lower_only ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_assemble_train(cgp_handle* h, int dim, int B, double* M, long ld, long sM, const double* x, long sx,
+                          const double* diag, long sd, const int* ns, long Np, bool lower_only) {
+    return dim == 1 ? launch_assemble_train_t<1>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only)
+                    : launch_assemble_train_t<2>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only);
+}
+
+int launch_assemble_cross(cgp_handle* h, int dim, int B, double* Mrows, long ld, long sM, const double* x, long sx,
+                          const double* xnew, long sxn, const int* ns, long Np, long Mp, long m) {
+    dim3 g((unsigned)(Np / 128), (unsigned)(Mp / 64), (unsigned)B);
+    if (dim == 1)
+        hipLaunchKernelGGL((k_assemble_cross<1>), g, dim3(256), 0, h->stream, Mrows, ld, sM, x, sx, xnew, sxn, ns,
+                           (const KParams*)h->bkp.p, (int)m);
+    else
+        hipLaunchKernelGGL((k_assemble_cross<2>), g, dim3(256), 0, h->stream, Mrows, ld, sM, x, sx, xnew, sxn, ns,
+                           (const KParams*)h->bkp.p, (int)m);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// mu / var for the m cross rows [Np, Np+m) against z = last tall row; block m adds the log-likelihood
+int launch_finish(cgp_handle* h, Prob& P, long m, bool with_loglik, bool has_mean, double kss_noise) {
+    StageScope sc(h, ST_FINISH);
+    const long blocks = m + (with_loglik ? 1 : 0);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)blocks, 1, P.B), dim3(256), 0, h->stream, P.M, P.Np, P.sM, (int)P.Np,
+                       (int)P.Np, (int)(P.R - 1), (int)m, has_mean ? P.mean : nullptr, (const KParams*)h->bkp.p,
+                       kss_noise, P.ldp, P.sLd, (int)(P.Np / NB), P.ns, P.mu, P.var, P.sOut, P.scal);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// The residual row r always sits in the LAST tall row (R-1), so prediction rows can be
+// re-assembled later without moving it; the sweep turns it into z = L^-1 r.
+__global__ void k_put_resid_row(double* __restrict__ M, long ld, long sM, long row, const double* __restrict__ r,
+                                long sr, const int* __restrict__ ns) {
+    const int b = blockIdx.z;
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ld) M[(long)b * sM + row * ld + c] = (c < ns[b]) ? r[(long)b * sr + c] : 0.;
+}
+
+__global__ void k_fill(double* p, long n, double v) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+extern "C" {
+
+int cgp_version(void) { return 1; }
+
+int cgp_device_count(int* count) {
+    if (!count) return CGP_E_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return e == hipSuccess ? CGP_OK : CGP_E_HIP;
+}
+
+int cgp_create(int device, cgp_handle** out) {
+    if (!out) return CGP_E_ARG;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || device < 0 || device >= c) return CGP_E_HIP;
+    cgp_handle* h = new cgp_handle();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return CGP_E_HIP;
+    }
+    *out = h;
+    return CGP_OK;
+}
+
+int cgp_destroy(cgp_handle* h) {
+    if (!h) return CGP_E_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf* all[] = {&h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bz, &h->bws, &h->bldp, &h->binfo, &h->bns,
+                     &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
+                     &h->box, &h->boxn, &h->bzero, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qz, &h->qws,
+                     &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
+    for (DevBuf* b : all) free_buf(*b);
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return CGP_OK;
+}
+
+const char* cgp_last_error(cgp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int cgp_synchronize(cgp_handle* h) {
+    if (!h) return CGP_E_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int begin_call(cgp_handle* h) {
+    if (!h) return CGP_E_ARG;
+    h->err.clear();
+    HIPCHK(hipSetDevice(h->device));
+    CHK(leaf_attr_once(h));
+    CHK(ensure(h, h->bkp, sizeof(KParams)));
+    return 0;
+}
+
+int upload_padded(cgp_handle* h, DevBuf& b, const double* src, size_t count, size_t padded) {
+    CHK(ensure(h, b, padded * sizeof(double)));
+    HIPCHK(hipMemsetAsync(b.p, 0, padded * sizeof(double), h->stream));
+    if (src && count) HIPCHK(hipMemcpyAsync(b.p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+// (re)bind the single-object Prob to the handle's buffers for `tall` extra rows
+int bind_single(cgp_handle* h, long tall, bool keep_factor) {
+    Prob& P = h->P;
+    P.B = 1;
+    P.R = P.Np + tall;
+    P.sM = P.R * P.Np;
+    const size_t need = (size_t)P.R * P.Np * sizeof(double);
+    if (keep_factor) CHK(ensure_keep(h, h->bM, need, (size_t)P.Np * P.Np * sizeof(double)));
+    else CHK(ensure(h, h->bM, need));
+    P.M = (double*)h->bM.p;
+    const long nblk = P.Np / NB;
+    CHK(ensure(h, h->bz, P.Np * sizeof(double)));
+    if (!keep_factor) {
+        CHK(ensure(h, h->bws, nblk * 8 * 256 * sizeof(double)));
+        CHK(ensure(h, h->bldp, nblk * sizeof(double)));
+        CHK(ensure(h, h->binfo, sizeof(int)));
+        CHK(ensure(h, h->bscal, 2 * sizeof(double)));
+    }
+    P.z = (double*)h->bz.p;
+    P.wsW = (double*)h->bws.p; P.sW = nblk * 8 * 256;
+    P.ldp = (double*)h->bldp.p; P.sLd = nblk;
+    P.info = (int*)h->binfo.p;
+    P.scal = (double*)h->bscal.p;
+    P.x = (double*)h->bx.p; P.sx = 0;
+    P.r = (double*)h->br.p; P.sr = 0;
+    P.diag = (double*)h->bdiag.p; P.sd = 0;
+    P.ns = (int*)h->bns.p;
+    return 0;
+}
+
+int put_resid_row(cgp_handle* h, Prob& P) {
+    hipLaunchKernelGGL(k_put_resid_row, dim3((unsigned)((P.Np + 255) / 256), 1, P.B), dim3(256), 0, h->stream, P.M,
+                       P.Np, P.sM, P.R - 1, P.r, P.sr, P.ns);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean, double kss_noise) {
+    // device-only part of a fit: everything already in HBM (cgp_fit, cgp_batch_fit, cgp_bench_fit)
+    const long ld = P.Np, Mp = P.R - P.Np;
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int) * P.B, h->stream));
+    {
+        StageScope sc(h, ST_ASM_K);
+        CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true));
+    }
+    {
+        StageScope sc(h, ST_ASM_H);
+        // cross rows t < m; rows t >= m are zeros; then the residual row at R-1
+        CHK(launch_assemble_cross(h, P.dim, P.B, P.M + P.Np * ld, ld, P.sM, P.x, P.sx, P.xnew, P.sxn, P.ns, P.Np, Mp,
+                                  m));
+        CHK(put_resid_row(h, P));
+    }
+    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    HIPCHK(hipMemcpy2DAsync(P.z, P.Np * sizeof(double), P.M + (P.R - 1) * ld, P.sM * sizeof(double),
+                            P.Np * sizeof(double), P.B, hipMemcpyDeviceToDevice, h->stream));
+    CHK(launch_finish(h, P, m, true, has_mean, kss_noise));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resid, int64_t n) {
+    CHK(begin_call(h));
+    if ((dim != 1 && dim != 2) || !x || !resid || n <= 0) return fail(h, CGP_E_ARG, "cgp_fit_set_data: bad argument");
+    Prob& P = h->P;
+    P.dim = dim;
+    P.n = n;
+    P.Np = round_up(n, NB);
+    CHK(upload_padded(h, h->bx, x, (size_t)n * dim, (size_t)P.Np * dim));
+    CHK(upload_padded(h, h->br, resid, (size_t)n, (size_t)P.Np));
+    CHK(ensure(h, h->bns, sizeof(int)));
+    int ni = (int)n;
+    HIPCHK(hipMemcpyAsync(h->bns.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_data = true;
+    h->factored = false;
+    return CGP_OK;
+}
+
+int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* xnew, int64_t m,
+            const double* mean_new, double kss_noise, double* loglik, double* logdet, double* mu, double* var) {
+    CHK(begin_call(h));
+    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_fit: no data (call cgp_fit_set_data)");
+    if (!kp || m < 0 || (m > 0 && (!xnew || !mu))) return fail(h, CGP_E_ARG, "cgp_fit: bad argument");
+    Prob& P = h->P;
+    const long Mp = round_up(m + 1, NB);
+    CHK(bind_single(h, Mp, false));
+    HIPCHK(hipMemcpyAsync(h->bkp.p, kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+    CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
+    CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
+    CHK(upload_padded(h, h->bmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
+    CHK(ensure(h, h->bmu, Mp * sizeof(double)));
+    CHK(ensure(h, h->bvar, Mp * sizeof(double)));
+    P.diag = (double*)h->bdiag.p;
+    P.xnew = (double*)h->bxnew.p; P.sxn = 0;
+    P.mean = (double*)h->bmean.p;
+    P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = Mp;
+    CHK(device_fit(h, P, m, mean_new != nullptr, kss_noise));
+    double sc[2];
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (m > 0) {
+        HIPCHK(hipMemcpyAsync(mu, P.mu, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (loglik) *loglik = sc[0];
+    if (logdet) *logdet = sc[1];
+    h->factored = (info == 0);
+    h->last_m = m;
+    h->last_has_mean = mean_new != nullptr;
+    h->last_kss_noise = kss_noise;
+    return info;
+}
+
+int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* mean_new, double kss_noise,
+                    double* mu, double* var, double* cov) {
+    CHK(begin_call(h));
+    if (!h->factored) return fail(h, CGP_E_STATE, "cgp_fit_predict: no factor (call cgp_fit first)");
+    if (!xnew || m <= 0 || !mu) return fail(h, CGP_E_ARG, "cgp_fit_predict: bad argument");
+    Prob& P = h->P;
+    const long Mp = round_up(m + 1, NB);
+    CHK(bind_single(h, Mp, true));
+    const long ld = P.Np;
+    CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
+    CHK(upload_padded(h, h->bmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
+    CHK(ensure(h, h->bmu, Mp * sizeof(double)));
+    CHK(ensure(h, h->bvar, Mp * sizeof(double)));
+    P.xnew = (double*)h->bxnew.p; P.sxn = 0;
+    P.mean = (double*)h->bmean.p;
+    P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = Mp;
+    CHK(launch_assemble_cross(h, P.dim, 1, P.M + P.Np * ld, ld, P.sM, P.x, 0, P.xnew, 0, P.ns, P.Np, Mp, m));
+    // rows are solved in 64-row groups, so the raw residual row rides along again with H
+    CHK(put_resid_row(h, P));
+    CHK(factor_range(h, P, 0, P.Np, P.Np, P.R, false));
+    CHK(launch_finish(h, P, m, false, mean_new != nullptr, kss_noise));
+    HIPCHK(hipMemcpyAsync(mu, P.mu, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (cov) {
+        // K(new,new; nugget) - W W^T, full matrix   [Gaussian_process.py:356-361]
+        CHK(ensure(h, h->bC, (size_t)Mp * Mp * sizeof(double)));
+        CHK(ensure(h, h->bdiag2, Mp * sizeof(double)));
+        CHK(ensure(h, h->bns2, sizeof(int)));
+        CHK(ensure(h, h->bout, (size_t)m * m * sizeof(double)));
+        int mi = (int)m;
+        HIPCHK(hipMemcpyAsync(h->bns2.p, &mi, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mp, kss_noise);
+        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, Mp, 0, P.xnew, 0, (double*)h->bdiag2.p, 0,
+                                  (int*)h->bns2.p, Mp, false));
+        CHK(launch_gemm(h, 1, (double*)h->bC.p, Mp, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, Mp, Mp, P.Np, false,
+                        -1.0, 1.0));
+        hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->bC.p, Mp,
+                           (double*)h->bout.p, (int)m, 0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(cov, h->bout.p, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// explicit inverse from the factor in P.M: W = I L^-T on Np tall rows, then Kinv = W W^T into bC
+int device_inverse(cgp_handle* h) {
+    Prob& P = h->P;
+    CHK(bind_single(h, P.Np, true));
+    const long ld = P.Np;
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.Np * ld, ld, (int)P.Np);
+    HIPCHK(hipGetLastError());
+    CHK(factor_range(h, P, 0, P.Np, P.Np, P.R, false));
+    CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, P.Np, P.Np, P.Np, false,
+                    1.0, 0.0));
+    return 0;
+}
+
+int square_to_host(cgp_handle* h, const double* src, long ld, long n, int mode, double* out) {
+    CHK(ensure(h, h->bout, (size_t)n * n * sizeof(double)));
+    hipLaunchKernelGGL(k_extract_square, dim3(512), dim3(256), 0, h->stream, src, ld, (double*)h->bout.p, (int)n, mode);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->bout.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgp_fit_fetch(cgp_handle* h, int which, double* out) {
+    CHK(begin_call(h));
+    if (!out) return fail(h, CGP_E_ARG, "cgp_fit_fetch: null output");
+    Prob& P = h->P;
+    if (which == CGP_MAT_K) {
+        if (!h->have_data || !h->bdiag.p) return fail(h, CGP_E_STATE, "cgp_fit_fetch(K): no fit yet");
+        CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
+        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, P.Np, 0, P.x, 0, P.diag, 0, P.ns, P.Np, false));
+        return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 0, out);
+    }
+    if (!h->factored) return fail(h, CGP_E_STATE, "cgp_fit_fetch: no factor");
+    if (which == CGP_MAT_L) return square_to_host(h, P.M, P.Np, P.n, 1, out);
+    if (which == CGP_MAT_KINV) {
+        CHK(device_inverse(h));
+        return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 0, out);
+    }
+    return fail(h, CGP_E_ARG, "cgp_fit_fetch: unknown matrix id");
+}
+
+int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, double* inv_out,
+                         double* logdet_out) {
+    CHK(begin_call(h));
+    if (!K || n <= 0 || ldk < n || !inv_out) return fail(h, CGP_E_ARG, "cgp_cholesky_inverse: bad argument");
+    Prob& P = h->P;
+    P.dim = 0;
+    P.n = n;
+    P.Np = round_up(n, NB);
+    h->have_data = false;
+    h->factored = false;
+    CHK(bind_single(h, 0, false));
+    CHK(ensure(h, h->bC, (size_t)std::max<long>(n * ldk, P.Np * P.Np) * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->bC.p, K, (size_t)n * ldk * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pad_square, dim3(512), dim3(256), 0, h->stream, (const double*)h->bC.p, (long)ldk, P.M,
+                       P.Np, (int)n, (int)P.Np);
+    HIPCHK(hipGetLastError());
+    CHK(ensure(h, h->bns, sizeof(int)));
+    int ni = (int)n;
+    HIPCHK(hipMemcpyAsync(h->bns.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    P.ns = (int*)h->bns.p;
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
+    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    const long nblk = P.Np / NB;
+    std::vector<double> parts(nblk);
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(parts.data(), P.ldp, nblk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (info != 0) return info;
+    double ld_sum = 0.;
+    for (double v : parts) ld_sum += v;
+    if (logdet_out) *logdet_out = ld_sum;
+    h->factored = true;
+    CHK(device_inverse(h));
+    return square_to_host(h, (double*)h->bC.p, P.Np, n, 0, inv_out);
+}
+
+int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xnew, int64_t m, const double* kp,
+            const double* diag, double* out, int64_t ld) {
+    CHK(begin_call(h));
+    if ((dim != 1 && dim != 2) || !x || n <= 0 || !kp || !out || ld < n || (xnew && m <= 0))
+        return fail(h, CGP_E_ARG, "cgp_rbf: bad argument");
+    const long Np = round_up(n, NB);
+    HIPCHK(hipMemcpyAsync(h->bkp.p, kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+    CHK(upload_padded(h, h->box, x, (size_t)n * dim, (size_t)Np * dim));
+    CHK(ensure(h, h->bns2, sizeof(int)));
+    int ni = (int)n;
+    HIPCHK(hipMemcpyAsync(h->bns2.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!xnew) {
+        CHK(upload_padded(h, h->bdiag2, diag, diag ? (size_t)n : 0, (size_t)Np));
+        CHK(ensure(h, h->bC, (size_t)Np * Np * sizeof(double)));
+        CHK(launch_assemble_train(h, dim, 1, (double*)h->bC.p, Np, 0, (double*)h->box.p, 0, (double*)h->bdiag2.p, 0,
+                                  (int*)h->bns2.p, Np, false));
+        HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), n,
+                                hipMemcpyDeviceToHost, h->stream));
+    } else {
+        const long Mp = round_up(m, NB);
+        CHK(upload_padded(h, h->boxn, xnew, (size_t)m * dim, (size_t)Mp * dim));
+        CHK(ensure(h, h->bC, (size_t)Mp * Np * sizeof(double)));
+        CHK(launch_assemble_cross(h, dim, 1, (double*)h->bC.p, Np, 0, (double*)h->box.p, 0, (double*)h->boxn.p, 0,
+                                  (int*)h->bns2.p, Np, Mp, m));
+        HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), m,
+                                hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
+
+int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
+                  const double* diag, const double* kp, const double* xnew, int64_t m, const double* mean_new,
+                  double kss_noise, double* loglik, int32_t* info, double* mu, double* var) {
+    CHK(begin_call(h));
+    if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid || !kp || m < 0 || (m > 0 && (!xnew || !mu)))
+        return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
+    long nmax = 0;
+    for (long b = 0; b < B; ++b) {
+        if (ns[b] <= 0) return fail(h, CGP_E_ARG, "cgp_batch_fit: ns[b] <= 0");
+        nmax = std::max<long>(nmax, ns[b]);
+    }
+    Prob& Q = h->Q;
+    Q.B = (int)B; Q.dim = dim; Q.n = nmax;
+    Q.Np = round_up(nmax, NB);
+    const long Mp = round_up(m + 1, NB);
+    Q.R = Q.Np + Mp;
+    Q.sM = Q.R * Q.Np;
+    const long Np = Q.Np, nblk = Np / NB;
+    // pack ragged host arrays into padded [B][Np] layouts
+    std::vector<double> hx((size_t)B * Np * dim, 0.), hr((size_t)B * Np, 0.), hd((size_t)B * Np, 0.);
+    std::vector<int> hn(B);
+    long off = 0;
+    for (long b = 0; b < B; ++b) {
+        const long nb = ns[b];
+        hn[b] = (int)nb;
+        std::memcpy(&hx[(size_t)b * Np * dim], x + off * dim, nb * dim * sizeof(double));
+        std::memcpy(&hr[(size_t)b * Np], resid + off, nb * sizeof(double));
+        if (diag) std::memcpy(&hd[(size_t)b * Np], diag + off, nb * sizeof(double));
+        off += nb;
+    }
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
+    CHK(ensure(h, h->qx, hx.size() * sizeof(double)));
+    CHK(ensure(h, h->qr, hr.size() * sizeof(double)));
+    CHK(ensure(h, h->qdiag, hd.size() * sizeof(double)));
+    CHK(ensure(h, h->qns, B * sizeof(int)));
+    CHK(ensure(h, h->qz, (size_t)B * Np * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
+    CHK(ensure(h, h->qinfo, B * sizeof(int)));
+    CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
+    CHK(ensure(h, h->qmu, (size_t)B * Mp * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * Mp * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->qx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qr.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qdiag.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->bkp.p, kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+    CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)Mp * dim));
+    CHK(upload_padded(h, h->qmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
+    Q.M = (double*)h->qM.p;
+    Q.x = (double*)h->qx.p; Q.sx = Np * dim;
+    Q.r = (double*)h->qr.p; Q.sr = Np;
+    Q.diag = (double*)h->qdiag.p; Q.sd = Np;
+    Q.xnew = (double*)h->qxnew.p; Q.sxn = 0;
+    Q.z = (double*)h->qz.p;
+    Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
+    Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
+    Q.info = (int*)h->qinfo.p;
+    Q.ns = (int*)h->qns.p;
+    Q.mean = (double*)h->qmean.p;
+    Q.mu = (double*)h->qmu.p; Q.var = (double*)h->qvar.p; Q.sOut = Mp;
+    Q.scal = (double*)h->qscal.p;
+    CHK(device_fit(h, Q, m, mean_new != nullptr, kss_noise));
+    std::vector<double> sc((size_t)B * 2);
+    std::vector<int> hinfo(B);
+    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (m > 0) {
+        HIPCHK(hipMemcpy2DAsync(mu, m * sizeof(double), Q.mu, Mp * sizeof(double), m * sizeof(double), B,
+                                hipMemcpyDeviceToHost, h->stream));
+        if (var)
+            HIPCHK(hipMemcpy2DAsync(var, m * sizeof(double), Q.var, Mp * sizeof(double), m * sizeof(double), B,
+                                    hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (long b = 0; b < B; ++b) {
+        if (loglik) loglik[b] = sc[2 * b];
+        if (info) info[b] = hinfo[b];
+    }
+    return CGP_OK;
+}
+
+int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms) {
+    CHK(begin_call(h));
+    if (iters <= 0 || !ms_per_fit) return fail(h, CGP_E_ARG, "cgp_bench_fit: bad argument");
+    if (!h->have_data || !h->P.M || !h->P.xnew) return fail(h, CGP_E_STATE, "cgp_bench_fit: run cgp_fit first");
+    Prob& P = h->P;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    h->profiling = false;
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) CHK(device_fit(h, P, h->last_m, h->last_has_mean, h->last_kss_noise));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_fit = (double)ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stage_ms) {
+        for (int i = 0; i < 8; ++i) stage_ms[i] = 0.;
+        h->profiling = true;
+        h->gemm_flops = 0.;
+        h->gemm_launches = 0;
+        const int reps = std::min(iters, 3);
+        for (int i = 0; i < reps; ++i) CHK(device_fit(h, P, h->last_m, h->last_has_mean, h->last_kss_noise));
+        h->profiling = false;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (auto& r : h->recs) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+            stage_ms[r.stage] += (double)t / reps;
+            h->pool.push_back(r.a);
+            h->pool.push_back(r.b);
+        }
+        h->recs.clear();
+        stage_ms[6] = (double)h->gemm_launches / reps;
+        stage_ms[7] = h->gemm_flops / reps;
+    }
+    return CGP_OK;
+}
+
+int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs) {
+    CHK(begin_call(h));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    CHK(ensure(h, h->bout, 1ull << 30));
+    if (mfma_f64_tflops) {
+        const int iters = 20000, blocks = 256 * 2;
+        hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, h->stream, (double*)h->bout.p, 200);
+        HIPCHK(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, h->stream, (double*)h->bout.p, iters);
+        HIPCHK(hipEventRecord(e1, h->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)blocks * 4 /*waves*/ * iters * 4 /*mfma per iter*/ * 2048.;
+        *mfma_f64_tflops = flops / (ms * 1e-3) / 1e12;
+    }
+    if (hbm_write_gbs) {
+        const long n2 = (1l << 30) / 16;
+        hipLaunchKernelGGL(k_stream_store, dim3(2048), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
+        HIPCHK(hipEventRecord(e0, h->stream));
+        for (int i = 0; i < 5; ++i)
+            hipLaunchKernelGGL(k_stream_store, dim3(2048), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
+        HIPCHK(hipEventRecord(e1, h->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *hbm_write_gbs = 5.0 * (double)(1l << 30) / (ms * 1e-3) / 1e9;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return CGP_OK;
+}
+
+int cgp_selftest_mfma(cgp_handle* h) {
+    CHK(begin_call(h));
+    double A[256], B[256], C[256], D[512], ref[256], ref2[256];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            A[i * 16 + j] = (double)((i * 3 + j * 5) % 7 - 3);
+            B[i * 16 + j] = (double)((i * 7 + j * 2 + 1) % 11 - 5);      // asymmetric
+            C[i * 16 + j] = (double)(i - 2 * j);
+        }
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double s = C[i * 16 + j];
+            for (int k = 0; k < 16; ++k) s += A[i * 16 + k] * B[k * 16 + j];
+            ref[i * 16 + j] = s;
+        }
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double s = 0.;
+            for (int k = 0; k < 16; ++k) s += A[i * 16 + k] * ref[k * 16 + j];
+            ref2[i * 16 + j] = s;
+        }
+    CHK(ensure(h, h->bout, 2048 * sizeof(double)));
+    double* d = (double*)h->bout.p;
+    HIPCHK(hipMemcpyAsync(d, A, sizeof(A), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + 256, B, sizeof(B), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + 512, C, sizeof(C), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, h->stream, d, d + 256, d + 512, d + 768);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(D, d + 768, sizeof(D), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 256; ++i) {
+        if (D[i] != ref[i]) return fail(h, 1, "f64 MFMA A/B/D lane map mismatch");
+        if (D[256 + i] != ref2[i]) return fail(h, 2, "f64 MFMA D-as-B chaining mismatch");
+    }
+    return CGP_OK;
+}
+
+}  // extern "C"

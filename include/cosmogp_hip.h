@@ -1,0 +1,151 @@
+/*
+ * cosmogp_hip.h -- C ABI of libcosmogp_hip.so, the MI355X (gfx950) implementation of
+ * the cosmogp GP hot path: RBF covariance assembly + blocked Cholesky factor/solve.
+ *
+ * This is the drop-in boundary.  The reference (PFLeget/cosmogp) has no FFI of its own;
+ * its plugin seam is:
+ *   - two module-level callables bound at import, cosmogp/Gaussian_process.py:6-9
+ *       svd(matrix, return_logdet=False) / chol(matrix, return_logdet=False)
+ *     (satisfied by an optional external C++ binding `svd_tmv` or by
+ *     cosmogp/inv_matrix.py:4-31), and
+ *   - the kernel callable bound per instance by name, cosmogp/Gaussian_process.py:140-154
+ *       kernel(x, hyperparameter, new_x=None, nugget=0., floor=0., y_err=None) -> ndarray
+ *     implemented in cosmogp/kernel.py:25-155.
+ * The entry points below are what a ctypes binding for that seam calls; the operator-level
+ * functions mirror the seam 1:1, the fused-level functions keep the N x N matrices on the
+ * device for the callers in cosmogp/Gaussian_process.py (log_likelihood_gp :13-75,
+ * get_prediction :270-338, get_covariance_matrix :340-361).
+ *
+ * Conventions
+ *   - all pointers are HOST pointers to C-contiguous float64 / int64 unless a name starts with d_
+ *   - inputs are never modified (the reference calls scipy with overwrite_a=False,
+ *     cosmogp/inv_matrix.py:23); outputs are caller-allocated
+ *   - return value: 0 = ok; > 0 = LAPACK-style info (1-based index of the first
+ *     non-positive pivot: the reference raises numpy.linalg.LinAlgError there,
+ *     cosmogp/inv_matrix.py:23); < 0 = CGP_E_* (argument / HIP error, text via cgp_last_error)
+ *   - thread-compatible: one handle per thread; each handle owns one HIP stream and its
+ *     device workspaces; calls on one handle are serialised by the caller
+ *   - no torch / numpy types cross this boundary.
+ *
+ * Kernel parameters ("kp", 6 doubles), computed by the host exactly as the reference does:
+ *   kp[0] amp_train  multiplies exp() in the train-train matrix
+ *                    1D: h0**2 (kernel.py:72); 2D: 1.0 -- the reference omits sigma^2 there
+ *                    (kernel.py:146) -- or h0**2 in corrected mode
+ *   kp[1] amp_cross  multiplies exp() in the cross matrix: h0**2 (kernel.py:72, :141)
+ *   kp[2..5]         1D: kp[2] = h1**2 (kernel.py:72)
+ *                    2D: VI = inv_l row-major [VI00, VI01, VI10, VI11] (kernel.py:127-130)
+ * The diagonal term (y_err**2 + floor**2 + nugget**2, kernel.py:74-75/:150-151) is passed as a
+ * length-n vector `diag` evaluated by the host in the reference's operation order.
+ */
+#ifndef COSMOGP_HIP_H
+#define COSMOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cgp_handle cgp_handle;
+
+enum {
+    CGP_OK = 0,
+    CGP_E_ARG = -1,      /* bad argument */
+    CGP_E_HIP = -2,      /* HIP runtime error */
+    CGP_E_STATE = -3,    /* call order (e.g. predict before factor) */
+    CGP_E_NOMEM = -4
+};
+
+enum { CGP_DIM_1D = 1, CGP_DIM_2D = 2 };
+
+/* which matrix cgp_fit_fetch returns */
+enum { CGP_MAT_K = 0, CGP_MAT_L = 1, CGP_MAT_KINV = 2 };
+
+/* ---- library / device ------------------------------------------------------------- */
+int cgp_version(void);                         /* ABI version, currently 1 */
+int cgp_device_count(int* count);
+int cgp_create(int device, cgp_handle** out);
+int cgp_destroy(cgp_handle* h);
+const char* cgp_last_error(cgp_handle* h);     /* text of the last <0 status ("" if none) */
+int cgp_synchronize(cgp_handle* h);
+
+/* ---- operator level: mirrors the reference seam 1:1 -------------------------------- */
+
+/* kernel(x, hyp, new_x, nugget, floor, y_err)  -- cosmogp/kernel.py:25-77 (dim 1), :80-155 (dim 2).
+ * x: n points (n doubles, or n x 2 AoS).  xnew == NULL: train-train, out is (n, n) with `diag`
+ * (n doubles, may be NULL = zeros) added on the diagonal.  xnew != NULL: cross matrix, out is
+ * (m, n), rows = new points, no diagonal term.  ld = row stride of out in doubles (>= n). */
+int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n,
+            const double* xnew, int64_t m, const double* kp, const double* diag,
+            double* out, int64_t ld);
+
+/* chol(matrix, return_logdet=True) -- cosmogp/inv_matrix.py:21-31.  K: (n, n) row stride ldk,
+ * symmetric positive definite (lower triangle is read).  inv_out: (n, n) dense, row stride n.
+ * logdet_out may be NULL.  Returns info > 0 when K is not positive definite. */
+int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
+                         double* inv_out, double* logdet_out);
+
+/* ---- fused level: one object's fit, matrices stay in HBM ---------------------------- */
+
+/* Upload one object: coordinates x (n or n x 2) and residual r = y - y0 (n doubles).
+ * Replaces any previous object on this handle. */
+int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resid, int64_t n);
+
+/* Assemble K(kp, diag) on the device, factor it (lower Cholesky, in place) and solve the
+ * residual row; optionally, in the same pass, assemble the cross matrix for m new points,
+ * solve it and produce the prediction.
+ *   diag      n doubles (NULL = zeros)
+ *   xnew      m points, or NULL (m = 0): log-likelihood only
+ *   mean_new  m doubles added to the predicted mean (NULL = 0)       [Gaussian_process.py:335]
+ *   kss_noise scalar diagonal term of K(new,new): (0**2 + floor**2 + nugget**2); the device
+ *             adds it to amp_train like kernel.py:74-75 does                [Gaussian_process.py:357]
+ *   loglik    -1/2 r'K^-1 r - n/2 log(2 pi) - 1/2 logdet             [Gaussian_process.py:68-73]
+ *   mu        m doubles: H K^-1 r + mean_new                          [Gaussian_process.py:334]
+ *   var       m doubles or NULL: diag(K** - H K^-1 H')               [Gaussian_process.py:359-361]
+ * Returns info > 0 if K is not positive definite (outputs are then NaN). */
+int cgp_fit(cgp_handle* h, const double* kp, const double* diag,
+            const double* xnew, int64_t m, const double* mean_new, double kss_noise,
+            double* loglik, double* logdet, double* mu, double* var);
+
+/* Prediction on further points with the factor left by the last cgp_fit (same kp).
+ * cov: NULL or (m, m) dense = K(new,new; nugget) - H K^-1 H'  [Gaussian_process.py:356-361] */
+int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* mean_new,
+                    double kss_noise, double* mu, double* var, double* cov);
+
+/* Lazy attributes of the reference object (kernel_matrix :262, inv_kernel_matrix :325):
+ * which = CGP_MAT_K (re-assembled, symmetric), CGP_MAT_L (lower factor, zeros above),
+ * CGP_MAT_KINV (explicit inverse from the factor).  out: (n, n) dense. */
+int cgp_fit_fetch(cgp_handle* h, int which, double* out);
+
+/* ---- batched: B independent objects of (possibly ragged) size, one launch sequence ---- */
+
+/* ns[B] sizes; x / resid / diag packed object after object (offsets = prefix sums of ns,
+ * times dim for x).  xnew: shared grid of m points (all objects), may be NULL (m = 0).
+ * Outputs: loglik[B], info[B] (0 or first bad pivot), mu[B*m], var[B*m] (may be NULL). */
+int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
+                  const double* x, const double* resid, const double* diag,
+                  const double* kp, const double* xnew, int64_t m, const double* mean_new,
+                  double kss_noise, double* loglik, int32_t* info, double* mu, double* var);
+
+/* ---- measurement hooks (bench.py / tests only) ------------------------------------- */
+
+/* Device-resident timing of the last cgp_fit shape: runs `iters` fits back to back with
+ * inputs already in HBM and no host copies, returns average milliseconds per fit measured
+ * with HIP events on the handle's stream.  stage_ms[8] (may be NULL) receives per-stage
+ * averages from a second, event-instrumented pass:
+ *   [0] assemble K  [1] potrf_diag  [2] trsm  [3] gemm update  [4] assemble cross
+ *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit */
+int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
+
+/* Bare v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 matrix ceiling (TFLOP/s),
+ * and a streaming-store kernel: measured HBM write ceiling (GB/s). */
+int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs);
+
+/* Checks the f64 MFMA operand / result lane maps the kernels rely on with exact integer
+ * data (asymmetric B).  Returns 0 when they hold. */
+int cgp_selftest_mfma(cgp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSMOGP_HIP_H */
