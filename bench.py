@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- GP fits/s and single-fit fp64 Cholesky GF/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: assemble K (RBF), blocked Cholesky with the cross matrix and the residual riding along
+as tall rows, predictive mean + variance at M points, log-likelihood.  No host copies inside the
+timed region (the PCIe-inclusive rate is noted in DESIGN.md, it is never `value`).
+
+Workloads (seeds fixed):
+  c3 (default at N=1)  2D RBF GP, N=8192, M=2500, single fit     -- the size BASELINE.json's metric names
+  c2                   1D RBF GP, N=4096, M=1024, single fit
+  c4                   1D light curves, N=512, M=19, 128 fits per GPU per step (1024 on 8 GPUs)
+N > 1: one process per GPU (torch.distributed.run), every rank fits its own objects (weak
+scaling, no data-path collective); RCCL is used for the barrier, the max-over-ranks of the timing
+and one all_gather of the predictions per step batch.
+
+Rank 0 prints ONE JSON line.  roofline = the dominant kernel (k_gemm_nt, fp64 MFMA): algorithmic
+flops per launch / average launch duration measured with HIP events on the kernel's own stream.
+cpu_baseline = the CPU oracle (NumPy/SciPy restatement of the reference) on the host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SPEC_FP64_MFMA_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (AMD datasheet class figure)
+SPEC_HBM_GBS = 8000.0
+
+
+def make_workload(name, rank=0):
+    from cosmogp_amd import kernel as K
+    if name == 'c3':
+        rng = np.random.default_rng(3 + 1000 * rank)
+        n, m = 8192, 2500
+        X = rng.uniform(0., 2048., (n, 2))
+        g = np.linspace(20., 2028., 50)
+        Xn = np.array([[a, b] for a in g for b in g])
+        y = np.sin(X[:, 0] / 150.) * np.cos(X[:, 1] / 170.) + 0.1 * rng.standard_normal(n)
+        hyp = [1., 110., 110., 0.]
+        return dict(dim=2, n=n, m=m, x=X, y=y, e=np.full(n, 0.1), xnew=Xn, hyp=hyp,
+                    kp=K.kernel_params_2d(hyp), label='2D RBF GP N=8192 M=2500 single fit (BASELINE config[2])')
+    if name == 'c2':
+        rng = np.random.default_rng(2 + 1000 * rank)
+        n, m = 4096, 1024
+        x = np.sort(rng.uniform(0., 400., n))
+        y = np.sin(0.05 * x) + 0.3 * np.cos(0.31 * x) + 0.1 * rng.standard_normal(n)
+        hyp = [1., 2.]
+        return dict(dim=1, n=n, m=m, x=x, y=y, e=np.full(n, 0.1), xnew=rng.uniform(0., 400., m), hyp=hyp,
+                    kp=K.kernel_params_1d(hyp), label='1D RBF GP N=4096 M=1024 single fit (BASELINE config[1])')
+    if name == 'c4':
+        B, n, m = 128, 512, 19
+        xs, ys, es = [], [], []
+        for i in range(B):
+            rng = np.random.default_rng(4000 + i + 1000 * rank)
+            x = np.sort(rng.uniform(-12., 42., n))
+            e = rng.uniform(0.02, 0.1, n)
+            xs.append(x)
+            es.append(e)
+            ys.append(0.5 * np.sin(x / 8.) + e * rng.standard_normal(n))
+        hyp = [0.5, 8.]
+        return dict(dim=1, n=n, m=m, B=B, xs=xs, ys=ys, es=es, xnew=np.linspace(-12., 42., m), hyp=hyp,
+                    kp=K.kernel_params_1d(hyp),
+                    label='128 x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3] / 8)')
+    raise SystemExit('unknown workload %r' % name)
+
+
+def cpu_baseline(wl):
+    """The oracle timed on the host cores on a bounded sample of the same workload."""
+    from oracle import cosmogp_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    t0 = time.perf_counter()
+    if 'B' in wl:
+        nfit = 4
+        for b in range(nfit):
+            Kc = orc.rbf_kernel_1d(wl['xs'][b], wl['hyp'], y_err=wl['es'][b])
+            H = orc.rbf_kernel_1d(wl['xs'][b], wl['hyp'], new_x=wl['xnew'])
+            orc.fit_predict_cho(Kc, wl['ys'][b], H, np.full(wl['m'], wl['hyp'][0] ** 2))
+        sample = '%d of the %d fits of one step (N=512, M=19), cho_factor/cho_solve form' % (nfit, wl['B'])
+    else:
+        nfit = 1
+        kern = orc.rbf_kernel_1d if wl['dim'] == 1 else orc.rbf_kernel_2d
+        Kc = kern(wl['x'], wl['hyp'], y_err=wl['e'])
+        H = kern(wl['x'], wl['hyp'], new_x=wl['xnew'])
+        t1 = time.perf_counter()
+        orc.fit_predict_cho(Kc, wl['y'], H, np.full(wl['m'], 1.0))
+        sample = ('1 full fit of the workload (assembly %.2f s + cho_factor/cho_solve/predict %.2f s); the '
+                  'reference\'s explicit-inverse form is ~3x more flops' % (t1 - t0, time.perf_counter() - t1))
+    dt = time.perf_counter() - t0
+    return dict(value=nfit / dt, unit='fits/s', cores=int(threads), kind='port', sample=sample,
+                seconds=round(dt, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl')
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world),
+              file=sys.stderr)
+
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    dev = _lib.Device(local_rank)
+    dev.selftest_mfma()
+    wl = make_workload(args.workload, rank)
+    batched = 'B' in wl
+
+    # ---- inputs to HBM + one checked fit (also sizes every workspace) -------------------------
+    if batched:
+        diags = [K.diag_term(wl['n'], e, 0., 0.) for e in wl['es']]
+
+        def step():
+            return dev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
+        ll, info, mu, var = step()
+        assert not info.any() and np.all(np.isfinite(mu))
+        units_per_step = wl['B']
+    else:
+        dev.set_data(wl['dim'], wl['x'], wl['y'])
+        diag = K.diag_term(wl['n'], wl['e'], 0., 0.)
+        ll, ld, mu, var = dev.fit(wl['kp'], diag, wl['xnew'], None, 0.)
+        assert np.isfinite(ll) and np.all(np.isfinite(mu)) and var.min() > -1e-9
+        units_per_step = 1
+
+    def sync_all():
+        dev._lib.cgp_synchronize(dev._h)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run_steps(k):
+        # k device-resident fits (or batches of fits) back to back on the handle's stream, then sync:
+        # the last cgp_fit / cgp_batch_fit left every input in HBM
+        if k > 0:
+            dev.bench_fit(k, stages=False)
+
+    run_steps(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    if dist is not None:                           # the one gather of the path: predictions of every rank
+        import torch
+        send = torch.from_numpy(np.ascontiguousarray(np.stack([np.ravel(mu), np.ravel(var)]))).cuda()
+        recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(recv.view(-1, *send.shape[1:]), send)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
+    roof, extra = None, {}
+    if not batched:
+        ms_fit, st = dev.bench_fit(min(args.steps, 5), stages=True)
+        n = wl['n']
+        gemm_ms, launches, flops = st[3], st[6], st[7]
+        ach = flops / (gemm_ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=None,
+                    kernel='k_gemm_nt (v_mfma_f64_16x16x4_f64)', launches_per_fit=int(launches),
+                    flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5))
+        potrf_ms = st[1] + st[2] + st[3]
+        chol_flops = n ** 3 / 3.0
+        # the sweep also carries the M+1 tall rows (n^2 (m+1) flops): time share by flops
+        sweep_flops = chol_flops + float(n) ** 2 * (wl['m'] + 1)
+        extra = dict(ms_per_fit_events=round(ms_fit, 4),
+                     stage_ms=dict(assemble_K=round(st[0], 4), potrf_diag=round(st[1], 4), trsm_panel=round(st[2], 4),
+                                   gemm_update=round(st[3], 4), assemble_cross=round(st[4], 4), finish=round(st[5], 4)),
+                     sweep_gflops=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),
+                     cholesky_gflops_equiv=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),
+                     assemble_K_GBs=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9, 1),
+                     assemble_K_frac_of_hbm=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9 / SPEC_HBM_GBS, 4))
+    if rank == 0:
+        mfma_tf, hbm_gbs = dev.microbench()
+        extra.update(measured_mfma_f64_ceiling_tflops=round(mfma_tf, 2), measured_hbm_write_gbs=round(hbm_gbs, 1))
+        if roof is not None:
+            roof['frac_of_measured_ceiling'] = round(roof['achieved'] / mfma_tf, 4)
+        value = n_gpus * args.steps * units_per_step / elapsed
+        line = dict(metric='gp_fits_per_sec', value=round(value, 4), unit='fits/s', n_gpus=n_gpus,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                    config=dict(workload=wl['label'], n=wl['n'], m=wl['m'], dim=wl['dim'],
+                                fits_per_step_per_gpu=units_per_step, parallelism='independent fits, 1 rank per GPU'),
+                    roofline=roof)
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(wl)
+        line['extra'] = extra
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -64,7 +64,8 @@ def load_library():
         lib.cgp_fit_predict.argtypes = [vp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp]
         lib.cgp_fit_fetch.argtypes = [vp, ctypes.c_int, _dp]
         lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
-                                      _i64, _dp, ctypes.c_double, _dp, ctypes.POINTER(ctypes.c_int32), _dp, _dp]
+                                      _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
+                                      ctypes.POINTER(ctypes.c_int32), _dp, _dp]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
         lib.cgp_microbench.argtypes = [vp, _dp, _dp]
         lib.cgp_selftest_mfma.argtypes = [vp]
@@ -109,6 +110,9 @@ class Device(object):
             raise HipUnavailable('cgp_create(device=%d) failed with status %d' % (self.index, st))
         self.dim = None
         self.n = None
+        #: bumped whenever the resident single-object factor is replaced (lazy attributes
+        #: of Gaussian_process check it before fetching from the device)
+        self.generation = 0
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -154,6 +158,7 @@ class Device(object):
             raise ValueError('expected a square matrix')
         inv = np.empty((n, n))
         ld = ctypes.c_double(0.)
+        self.generation += 1
         st = self._lib.cgp_cholesky_inverse(self._h, _ptr(K), n, n, _ptr(inv), ctypes.byref(ld))
         self._check(st, 'cgp_cholesky_inverse')
         return inv, ld.value
@@ -163,6 +168,7 @@ class Device(object):
         x = _f64(x)
         n = x.shape[0]
         resid = _f64(resid, (n,))
+        self.generation += 1
         self._check(self._lib.cgp_fit_set_data(self._h, dim, _ptr(x), _ptr(resid), n), 'cgp_fit_set_data')
         self.dim, self.n = dim, n
 
@@ -203,8 +209,10 @@ class Device(object):
         return out
 
     # ---- batched -------------------------------------------------------------------
-    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.):
-        """xs / resids / diags: lists of per-object arrays (ragged allowed).
+    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.,
+                  xnew_per_object=False):
+        """xs / resids / diags: lists of per-object arrays (ragged allowed).  xnew: (m,[2]) grid
+        shared by all objects, or (B, m,[2]) with xnew_per_object=True.
         Returns (loglik[B], info[B], mu[B,m] or None, var[B,m] or None)."""
         B = len(xs)
         ns = np.array([len(r) for r in resids], dtype=np.int64)
@@ -218,11 +226,14 @@ class Device(object):
             m, xn, mu, var, mn = 0, None, None, None, None
         else:
             xn = _f64(xnew)
-            m = xn.shape[0]
+            m = xn.shape[1] if xnew_per_object else xn.shape[0]
+            if xnew_per_object and xn.shape[0] != B:
+                raise ValueError('per-object grids need shape (B, m[, 2])')
             mu, var = np.empty((B, m)), np.empty((B, m))
             mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
         st = self._lib.cgp_batch_fit(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
-                                     _ptr(d), _ptr(kp), _ptr(xn), m, _ptr(mn), float(kss_noise), _ptr(ll),
+                                     _ptr(d), _ptr(kp), _ptr(xn), m, 1 if xnew_per_object else 0, _ptr(mn),
+                                     float(kss_noise), _ptr(ll),
                                      info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(mu), _ptr(var))
         self._check(st, 'cgp_batch_fit')
         return ll, info, mu, var

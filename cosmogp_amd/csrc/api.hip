@@ -57,6 +57,7 @@ struct cgp_handle {
     long last_m = 0;
     bool last_has_mean = false;
     double last_kss_noise = 0.;
+    bool last_was_batch = false;
     DevBuf bM, bx, br, bdiag, bxnew, bz, bws, bldp, binfo, bns, bmean, bmu, bvar, bscal, bkp;
     DevBuf bC, bout, bns2, bdiag2;            // scratch: square outputs
     DevBuf box, boxn, bzero;                  // operator-level scratch
@@ -454,6 +455,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
+    h->last_was_batch = false;
     h->last_m = m;
     h->last_has_mean = mean_new != nullptr;
     h->last_kss_noise = kss_noise;
@@ -624,8 +626,9 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xn
 }
 
 int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
-                  const double* diag, const double* kp, const double* xnew, int64_t m, const double* mean_new,
-                  double kss_noise, double* loglik, int32_t* info, double* mu, double* var) {
+                  const double* diag, const double* kp, const double* xnew, int64_t m, int xnew_per_object,
+                  const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu,
+                  double* var) {
     CHK(begin_call(h));
     if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid || !kp || m < 0 || (m > 0 && (!xnew || !mu)))
         return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
@@ -670,13 +673,22 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     HIPCHK(hipMemcpyAsync(h->qdiag.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->bkp.p, kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
-    CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)Mp * dim));
+    if (xnew_per_object && m > 0) {
+        std::vector<double> hxn((size_t)B * Mp * dim, 0.);
+        for (long b = 0; b < B; ++b)
+            std::memcpy(&hxn[(size_t)b * Mp * dim], xnew + (size_t)b * m * dim, m * dim * sizeof(double));
+        CHK(ensure(h, h->qxnew, hxn.size() * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->qxnew.p, hxn.data(), hxn.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+        CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)Mp * dim));
+    }
     CHK(upload_padded(h, h->qmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
     Q.M = (double*)h->qM.p;
     Q.x = (double*)h->qx.p; Q.sx = Np * dim;
     Q.r = (double*)h->qr.p; Q.sr = Np;
     Q.diag = (double*)h->qdiag.p; Q.sd = Np;
-    Q.xnew = (double*)h->qxnew.p; Q.sxn = 0;
+    Q.xnew = (double*)h->qxnew.p; Q.sxn = (xnew_per_object && m > 0) ? Mp * dim : 0;
     Q.z = (double*)h->qz.p;
     Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
     Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
@@ -702,14 +714,19 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
     }
+    h->last_was_batch = true;
+    h->last_m = m;
+    h->last_has_mean = mean_new != nullptr;
+    h->last_kss_noise = kss_noise;
     return CGP_OK;
 }
 
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms) {
     CHK(begin_call(h));
     if (iters <= 0 || !ms_per_fit) return fail(h, CGP_E_ARG, "cgp_bench_fit: bad argument");
-    if (!h->have_data || !h->P.M || !h->P.xnew) return fail(h, CGP_E_STATE, "cgp_bench_fit: run cgp_fit first");
-    Prob& P = h->P;
+    if (!h->last_was_batch && (!h->have_data || !h->P.M || !h->P.xnew))
+        return fail(h, CGP_E_STATE, "cgp_bench_fit: run cgp_fit or cgp_batch_fit first");
+    Prob& P = h->last_was_batch ? h->Q : h->P;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

@@ -1,0 +1,421 @@
+"""GP regressor objects -- host mirror of cosmogp/Gaussian_process.py.
+
+Same class names, constructor arguments, methods and result attributes as the reference
+(Gaussian_process.py:78-393), so scripts written for cosmogp run unchanged.  What differs
+is where the O(N^2)/O(N^3) work happens:
+
+  svd_method=False  the accelerated path.  Per object ONE call into libcosmogp_hip
+                    (cgp_fit): K is assembled in HBM, factored by the blocked MFMA
+                    Cholesky, and the cross matrix + residual ride along as extra rows,
+                    so log-likelihood, prediction and predictive variance come back as
+                    O(M) vectors.  N x N matrices never cross PCIe unless a caller reads
+                    .kernel_matrix / .inv_kernel_matrix / .covariance_matrix, which are
+                    lazy lists filled from the device on first access.
+  svd_method=True   the reference's default algorithm (SVD pseudo-inverse,
+                    inv_matrix.py:4-18), kept for its semantics on singular K.  K and H
+                    are assembled on the GPU, the SVD is SciPy on the host exactly like
+                    the reference (not a GPU target this round).
+
+Documented deviations from the reference (SURVEY.md 8a "quirks"):
+  * get_prediction with new_binning=None uses each object's own grid; the reference
+    indexes with a stale loop variable (Gaussian_process.py:330) and so uses the LAST
+    object's grid for every object.  REFERENCE_STALE_INDEX=True restores that.
+  * fit_nugget exists (False) from construction; the reference only creates it inside
+    find_hyperparameters (:242-245), so compute_log_likelihood first raises AttributeError.
+  * the 2D train-train sigma^2 omission is kept by default (kernel.SIGMA2_IN_TRAIN_2D).
+"""
+import numpy as np
+from scipy.optimize import fmin
+
+from . import _lib
+from . import kernel as _kernel
+from .inv_matrix import svd_inverse
+from .mean import return_mean
+
+REFERENCE_STALE_INDEX = False
+
+#: objects per batched launch sequence are capped so that B * (Np + 128) * Np * 8 bytes
+#: stays below this (HBM is 288 GB; leave room for several handles)
+BATCH_BYTES_LIMIT = 64 << 30
+
+
+class _LazyList(object):
+    """List-like whose items are produced (and cached) on first access: keeps the
+    reference's `gp.covariance_matrix[0]` / `gp.inv_kernel_matrix[sn]` idiom without moving
+    N x N matrices over PCIe when nobody looks at them."""
+
+    def __init__(self, n, producer):
+        self._n = n
+        self._producer = producer
+        self._items = {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._items:
+            self._items[i] = self._producer(i)
+        return self._items[i]
+
+    def __setitem__(self, i, value):
+        self._items[i] = value
+
+    def __iter__(self):
+        return (self[k] for k in range(self._n))
+
+
+def log_likelihood_gp(y, x_axis, kernel, hyperparameter, nugget, y_err=None, y_mean=None,
+                      svd_method=True, device=None):
+    """Log marginal likelihood of one object; same contract as Gaussian_process.py:13-75
+    (returns an ndarray of shape (1,)).  `kernel` is 'RBF1D' / 'RBF2D' or one of this
+    package's rbf_kernel_1d / rbf_kernel_2d callables."""
+    dim = _kernel_dim(kernel)
+    if y_mean is None:
+        y_mean = np.zeros_like(y)
+    y = np.asarray(y, dtype=np.float64)
+    resid = y - y_mean
+    n = len(x_axis)
+    if svd_method:
+        kern = _kernel.rbf_kernel_1d if dim == 1 else _kernel.rbf_kernel_2d
+        kmat = kern(x_axis, hyperparameter, nugget=nugget, y_err=y_err, device=device)
+        inv, logdet = svd_inverse(kmat, return_logdet=True)
+        ll = -0.5 * np.dot(resid, np.dot(inv, resid.reshape(n, 1)))
+        ll += -(n / 2.) * np.log((2 * np.pi))
+        ll -= 0.5 * logdet
+        return ll
+    dev = device if device is not None else _lib.default_device()
+    dev.set_data(dim, x_axis, np.ones(n) * resid)
+    ll, _, _, _ = dev.fit(_kparams(dim, hyperparameter), _kernel.diag_term(n, y_err, 0., nugget))
+    return np.array([ll])
+
+
+def _kernel_dim(kernel):
+    if kernel in ('RBF1D', _kernel.rbf_kernel_1d):
+        return 1
+    if kernel in ('RBF2D', _kernel.rbf_kernel_2d):
+        return 2
+    raise ValueError('kernel must be RBF1D / RBF2D (or rbf_kernel_1d / rbf_kernel_2d)')
+
+
+def _kparams(dim, hyperparameter):
+    return _kernel.kernel_params_1d(hyperparameter) if dim == 1 else _kernel.kernel_params_2d(hyperparameter)
+
+
+class Gaussian_process(object):
+    """Gaussian process regressor over a list of independent objects
+    (mirror of cosmogp.Gaussian_process, Gaussian_process.py:78-361)."""
+
+    def __init__(self, y, Time, kernel='RBF1D', y_err=None, diff=None, Mean_Y=None,
+                 Time_mean=None, substract_mean=False, device=None):
+        kernel_choice = ['RBF1D', 'RBF2D']
+        assert kernel in kernel_choice, '%s is not in implemented kernel' % (kernel)
+        self._dim = 1 if kernel == 'RBF1D' else 2
+        self._device = device
+        self.comm = None            # set to multigpu.Comm() to shard objects over ranks
+        if self._dim == 1:
+            self.kernel = _kernel.rbf_kernel_1d
+            sigma, L = _kernel.init_rbf(Time, y)
+            self.hyperparameters = np.array([sigma, L])
+        else:
+            self.kernel = _kernel.rbf_kernel_2d
+            sigma, L = _kernel.init_rbf(Time, y)
+            self.hyperparameters = np.array([sigma, L, L, 0.])
+        self.y = y
+        self.N_sn = len(y)
+        self.Time = Time
+        self.nugget = 0.
+        self.fit_nugget = False
+        if y_err is not None:
+            self.y_err = y_err
+        else:
+            self.y_err = [np.zeros(len(self.y[i])) for i in range(self.N_sn)]
+        self.Mean_Y = Mean_Y
+        self.Time_mean = Time_mean
+        self.substract_mean = substract_mean
+        self.diff = np.array([None] * self.N_sn) if diff is None else diff
+        if self.substract_mean or self.Mean_Y is not None:
+            self.y0 = [return_mean(self.y[i], self.Time[i], mean_y=self.Mean_Y,
+                                   mean_xaxis=self.Time_mean, diff=self.diff[i])
+                       for i in range(self.N_sn)]
+        else:
+            self.y0 = np.zeros(self.N_sn)
+        self.as_the_same_time = True
+        self._resident = None       # (device generation, object index) of the data in HBM
+        self._factor_token = None   # + (kp, nugget) of the factor in HBM
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = _lib.default_device()
+        return self._device
+
+    def _resid(self, sn):
+        return np.asarray(self.y[sn], dtype=np.float64) - self.y0[sn]
+
+    def _diag(self, sn, nugget):
+        return _kernel.diag_term(len(self.y[sn]), self.y_err[sn], 0., nugget)
+
+    def _my_objects(self):
+        if self.comm is None:
+            return list(range(self.N_sn))
+        return self.comm.my_units(self.N_sn)
+
+    def _batch_chunks(self, objs):
+        """Split object indices into chunks whose padded batch fits BATCH_BYTES_LIMIT."""
+        chunks, cur, cur_max = [], [], 0
+        for sn in objs:
+            n = len(self.y[sn])
+            np_ = (max(cur_max, n) + 127) // 128 * 128
+            if cur and (len(cur) + 1) * (np_ + 128) * np_ * 8 > BATCH_BYTES_LIMIT:
+                chunks.append(cur)
+                cur, cur_max = [], 0
+            cur.append(sn)
+            cur_max = max(cur_max, n)
+        if cur:
+            chunks.append(cur)
+        return chunks
+
+    def _fit_single(self, sn, kp, nugget, grid=None, new_y0=None, kss_noise=0.):
+        """One cgp_fit for object sn; its coordinates / residual are uploaded only when another
+        object (or another GP on the same handle) replaced them."""
+        dev = self.device
+        if self._resident != (dev.generation, sn):
+            dev.set_data(self._dim, self.Time[sn], self._resid(sn))
+            self._resident = (dev.generation, sn)
+        self._factor_token = None
+        out = dev.fit(kp, self._diag(sn, nugget), grid, new_y0, kss_noise)
+        self._factor_token = (dev.generation, sn, kp.tobytes(), float(nugget))
+        return out
+
+    def _ensure_factor(self, sn, kp, nugget):
+        """Make object sn's factor (for kp, nugget) the one in HBM; re-fit if it was replaced."""
+        dev = self.device
+        if (self._resident == (dev.generation, sn)
+                and self._factor_token == (dev.generation, sn, kp.tobytes(), float(nugget))):
+            return
+        self._fit_single(sn, kp, nugget)
+
+    # ------------------------------------------------------------------ likelihood
+    def compute_log_likelihood(self, Hyperparameter, svd_method=True):
+        """Summed log marginal likelihood of all objects for one hyperparameter set
+        (Gaussian_process.py:191-213); result in self.log_likelihood, shape (1,)."""
+        if self.fit_nugget:
+            Nugget = Hyperparameter[-1]
+            hyperparameter = Hyperparameter[:-1]
+        else:
+            Nugget = self.nugget
+            hyperparameter = Hyperparameter
+        objs = self._my_objects()
+        if svd_method:
+            per_obj = [log_likelihood_gp(self.y[sn], self.Time[sn], self.kernel, hyperparameter, Nugget,
+                                         y_err=self.y_err[sn], y_mean=self.y0[sn], svd_method=True,
+                                         device=self.device)[0] for sn in objs]
+        else:
+            per_obj = self._loglik_chol(objs, hyperparameter, Nugget)
+        if self.comm is not None:
+            per_obj = self.comm.gather_units(np.asarray(per_obj, dtype=np.float64), self.N_sn)
+        log_likelihood = 0
+        for v in per_obj:                       # object order, like the reference's loop
+            log_likelihood = log_likelihood + np.array([v])
+        self.log_likelihood = log_likelihood
+
+    def _loglik_chol(self, objs, hyperparameter, nugget):
+        dev = self.device
+        kp = _kparams(self._dim, hyperparameter)
+        if len(objs) == 1:
+            return [self._fit_single(objs[0], kp, nugget)[0]]
+        out = []
+        for chunk in self._batch_chunks(objs):
+            ll, info, _, _ = dev.batch_fit(self._dim, [self.Time[sn] for sn in chunk],
+                                           [self._resid(sn) for sn in chunk],
+                                           [self._diag(sn, nugget) for sn in chunk], kp)
+            bad = np.nonzero(info)[0]
+            if len(bad):
+                raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
+                                            ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
+            out.extend(ll.tolist())
+        return out
+
+    def find_hyperparameters(self, hyperparameter_guess=None, nugget=False, svd_method=True):
+        """Maximum-likelihood hyperparameters with Nelder-Mead (scipy.optimize.fmin), the
+        reference's driver (Gaussian_process.py:216-253); every evaluation of the objective is
+        one device call with the data already resident in HBM."""
+        if hyperparameter_guess is not None:
+            assert len(self.hyperparameters) == len(hyperparameter_guess), 'should be same len'
+            self.hyperparameters = hyperparameter_guess
+
+        def cost(hyper):
+            self.compute_log_likelihood(hyper, svd_method=svd_method)
+            return -self.log_likelihood[0]
+
+        start = [self.hyperparameters[i] for i in range(len(self.hyperparameters))]
+        self.fit_nugget = bool(nugget)
+        if self.fit_nugget:
+            start.append(1.)
+        best = fmin(cost, start, disp=False)
+        self.hyperparameters = np.array(self.hyperparameters, dtype=np.float64)
+        for i in range(len(self.hyperparameters)):
+            self.hyperparameters[i] = np.sqrt(best[i] ** 2)
+        if self.fit_nugget:
+            self.nugget = np.sqrt(best[-1] ** 2)
+
+    # ------------------------------------------------------------------ matrices
+    def compute_kernel_matrix(self):
+        """self.kernel_matrix = [K_sn] (Gaussian_process.py:256-267), produced lazily on the
+        device with the hyperparameters current at call time."""
+        hyp = np.array(self.hyperparameters, dtype=np.float64)
+        nugget = self.nugget
+
+        def make(sn):
+            return self.kernel(self.Time[sn], hyp, nugget=nugget, y_err=self.y_err[sn], device=self.device)
+
+        self.kernel_matrix = _LazyList(self.N_sn, make)
+
+    # ------------------------------------------------------------------ prediction
+    def _grid(self, sn):
+        if not self.as_the_same_time:
+            return self.new_binning
+        if REFERENCE_STALE_INDEX:
+            return self.new_binning[self.N_sn - 1]
+        return self.new_binning[sn]
+
+    def _new_y0(self, sn):
+        if self.substract_mean or self.Mean_Y is not None:
+            if self.as_the_same_time:
+                return self.y0[sn]
+            return return_mean(self.y[sn], self.Time[sn], new_x=self.new_binning, mean_y=self.Mean_Y,
+                               mean_xaxis=self.Time_mean, diff=self.diff[sn])
+        return 0.
+
+    def get_prediction(self, new_binning=None, COV=True, svd_method=True):
+        """Interpolate every object on new_binning (None: on its own grid) --
+        Gaussian_process.py:270-338.  Results: self.Prediction (list of (M,)),
+        self.variance (list of (M,), the diagonal of the predictive covariance; extension),
+        and with COV=True self.covariance_matrix (lazy list of (M, M))."""
+        if new_binning is None:
+            self.as_the_same_time = True
+            self.new_binning = self.Time
+        else:
+            self.as_the_same_time = False
+            self.new_binning = new_binning
+        self.compute_kernel_matrix()
+        hyp = np.array(self.hyperparameters, dtype=np.float64)
+        nugget = self.nugget
+        self.Prediction = [None] * self.N_sn
+        self.variance = [None] * self.N_sn
+        if svd_method:
+            self._predict_svd(hyp, nugget, COV)
+            return
+        dev = self.device
+        kp = _kparams(self._dim, hyp)
+        kss_noise = 0. ** 2 + 0. ** 2 + nugget ** 2          # kernel(new_grid, hyp, nugget=...) :357
+        objs = self._my_objects()
+        shared = not self.as_the_same_time
+        if len(objs) > 1 and shared:
+            for chunk in self._batch_chunks(objs):
+                _, info, mu, var = dev.batch_fit(self._dim, [self.Time[sn] for sn in chunk],
+                                                 [self._resid(sn) for sn in chunk],
+                                                 [self._diag(sn, nugget) for sn in chunk], kp,
+                                                 xnew=self.new_binning, kss_noise=kss_noise)
+                bad = np.nonzero(info)[0]
+                if len(bad):
+                    raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
+                                                ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
+                for k, sn in enumerate(chunk):
+                    new_y0 = self._new_y0(sn)
+                    self.warning_pf = new_y0
+                    self.Prediction[sn] = mu[k] + new_y0
+                    self.variance[sn] = var[k]
+        else:
+            for sn in objs:
+                new_y0 = self._new_y0(sn)
+                self.warning_pf = new_y0
+                _, _, mu, var = self._fit_single(sn, kp, nugget, self._grid(sn), new_y0, kss_noise)
+                self.Prediction[sn] = mu
+                self.variance[sn] = var
+        if self.comm is not None:
+            self.Prediction = self.comm.gather_unit_arrays(self.Prediction, self.N_sn)
+            self.variance = self.comm.gather_unit_arrays(self.variance, self.N_sn)
+
+        def make_inv(sn):
+            self._ensure_factor(sn, kp, nugget)
+            return dev.fetch(_lib.MAT_KINV)
+
+        self.inv_kernel_matrix = _LazyList(self.N_sn, make_inv)
+        if COV:
+            self._cov_state = (kp, nugget, kss_noise)
+            self.get_covariance_matrix()
+
+    def get_covariance_matrix(self):
+        """self.covariance_matrix = [K(new,new; nugget) - H K^-1 H^T] (Gaussian_process.py:340-361).
+        On the Cholesky path the full (M, M) matrix is built on the device
+        (K** - W W^T, one MFMA GEMM) when an item is first read."""
+        state = getattr(self, '_cov_state', None)
+        if state is None:
+            raise AttributeError('get_covariance_matrix needs get_prediction(svd_method=False) first')
+        kp, nugget, kss_noise = state
+        dev = self.device
+
+        def make(sn):
+            self._ensure_factor(sn, kp, nugget)
+            grid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
+            _, _, cov = dev.predict(grid, None, kss_noise, want_cov=True)
+            return cov
+
+        self.covariance_matrix = _LazyList(self.N_sn, make)
+
+    def _predict_svd(self, hyp, nugget, COV):
+        """Reference default (svd_method=True): SVD pseudo-inverse on the host, K / H from the GPU."""
+        self.inv_kernel_matrix = []
+        self.covariance_matrix = []
+        for sn in range(self.N_sn):
+            new_y0 = self._new_y0(sn)
+            self.warning_pf = new_y0
+            inv = svd_inverse(self.kernel_matrix[sn])
+            self.inv_kernel_matrix.append(inv)
+            H = self.kernel(self.Time[sn], hyp, new_x=self._grid(sn), device=self.device)
+            resid = self._resid(sn).reshape(len(self.y[sn]), 1)
+            self.Prediction[sn] = np.dot(H, np.dot(inv, resid)).T[0] + new_y0
+            if COV:
+                grid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
+                Hc = self.kernel(self.Time[sn], hyp, new_x=grid, device=self.device)
+                Kss = self.kernel(grid, hyp, nugget=nugget, device=self.device)
+                cov = -np.dot(Hc, np.dot(inv, Hc.T)) + Kss
+                self.covariance_matrix.append(cov)
+                self.variance[sn] = np.diag(cov).copy()
+
+
+class gaussian_process(Gaussian_process):
+    """One object (mirror of cosmogp.gaussian_process, Gaussian_process.py:365-379)."""
+
+    def __init__(self, y, Time, kernel='RBF1D', y_err=None, diff=None, Mean_Y=None,
+                 Time_mean=None, substract_mean=False, device=None):
+        if y_err is not None:
+            y_err = [y_err]
+        Gaussian_process.__init__(self, [y], [Time], kernel=kernel, y_err=y_err, Mean_Y=Mean_Y,
+                                  Time_mean=Time_mean, diff=diff, substract_mean=substract_mean,
+                                  device=device)
+
+
+class gaussian_process_nobject(Gaussian_process):
+    """n objects sharing hyperparameters (mirror of cosmogp.gaussian_process_nobject,
+    Gaussian_process.py:382-393)."""
+
+    def __init__(self, y, Time, kernel='RBF1D', y_err=None, diff=None, Mean_Y=None,
+                 Time_mean=None, substract_mean=False, device=None):
+        Gaussian_process.__init__(self, y, Time, kernel=kernel, y_err=y_err, diff=diff, Mean_Y=Mean_Y,
+                                  Time_mean=Time_mean, substract_mean=substract_mean, device=device)
+
+
+def gaussian_process_2d(y, Time, **kwargs):
+    """Convenience constructor named in BASELINE.json's north_star (no such symbol exists in
+    the reference): gaussian_process(..., kernel='RBF2D')."""
+    kwargs['kernel'] = 'RBF2D'
+    return gaussian_process(y, Time, **kwargs)

@@ -120,16 +120,20 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out);
 /* ---- batched: B independent objects of (possibly ragged) size, one launch sequence ---- */
 
 /* ns[B] sizes; x / resid / diag packed object after object (offsets = prefix sums of ns,
- * times dim for x).  xnew: shared grid of m points (all objects), may be NULL (m = 0).
+ * times dim for x).  xnew: m points -- one grid shared by all objects (xnew_per_object = 0,
+ * the new_binning of Gaussian_process.py:287-289) or B grids of m points each
+ * (xnew_per_object = 1; leave-one-out of cosmogp/pull.py:75-90) -- may be NULL (m = 0).
+ * mean_new: m doubles shared by all objects or NULL.
  * Outputs: loglik[B], info[B] (0 or first bad pivot), mu[B*m], var[B*m] (may be NULL). */
 int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
                   const double* x, const double* resid, const double* diag,
-                  const double* kp, const double* xnew, int64_t m, const double* mean_new,
-                  double kss_noise, double* loglik, int32_t* info, double* mu, double* var);
+                  const double* kp, const double* xnew, int64_t m, int xnew_per_object,
+                  const double* mean_new, double kss_noise, double* loglik, int32_t* info,
+                  double* mu, double* var);
 
 /* ---- measurement hooks (bench.py / tests only) ------------------------------------- */
 
-/* Device-resident timing of the last cgp_fit shape: runs `iters` fits back to back with
+/* Device-resident timing of the last cgp_fit / cgp_batch_fit: runs `iters` fits (or batches) back to back with
  * inputs already in HBM and no host copies, returns average milliseconds per fit measured
  * with HIP events on the handle's stream.  stage_ms[8] (may be NULL) receives per-stage
  * averages from a second, event-instrumented pass:

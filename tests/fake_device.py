@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE: a stand-in for cosmogp_amd._lib.Device built on the CPU oracle, used only
+by the CPU tests of the host logic (sharding over ranks, batching, lazy attributes) where no GPU
+exists.  It is never importable from the product package."""
+import numpy as np
+
+from oracle import cosmogp_oracle as orc
+
+
+def _kernel_from_kp(dim, kp):
+    """Rebuild oracle-callable kernels from a kp vector (include/cosmogp_hip.h)."""
+    kp = np.asarray(kp, dtype=np.float64)
+
+    def cross_or_train(x, xnew=None, diag=None):
+        x = np.asarray(x, dtype=np.float64)
+        other = x if xnew is None else np.asarray(xnew, dtype=np.float64)
+        if dim == 1:
+            d = x[None, :] - other[:, None]
+            arg = -0.5 * ((d * d) / kp[2])
+        else:
+            vi = kp[2:].reshape(2, 2)
+            dist = orc._mahalanobis_sq_then_sqrt(x, other, vi).T
+            arg = -0.5 * dist ** 2
+        if xnew is None:
+            k = kp[0] * np.exp(arg)
+            idx = np.arange(len(x))
+            k[idx, idx] = kp[0] + (0. if diag is None else diag)
+            return k
+        return kp[1] * np.exp(arg)
+
+    return cross_or_train
+
+
+class FakeDevice(object):
+    def __init__(self):
+        self.generation = 0
+        self.calls = []
+
+    def rbf(self, dim, x, kp, xnew=None, diag=None):
+        return _kernel_from_kp(dim, kp)(x, xnew, diag)
+
+    def set_data(self, dim, x, resid):
+        self.generation += 1
+        self.dim, self.x, self.r, self.n = dim, np.asarray(x, float), np.asarray(resid, float), len(resid)
+        self.calls.append('set_data')
+
+    def _one(self, dim, x, r, diag, kp, xnew, mean_new, kss_noise):
+        kern = _kernel_from_kp(dim, kp)
+        K = kern(x, None, diag)
+        try:
+            if xnew is None:
+                _, _, ll = orc.fit_predict_cho(K, r, np.zeros((0, len(r))), np.zeros(0))
+                return ll, None, None
+            H = kern(x, xnew)
+            mu, var, ll = orc.fit_predict_cho(K, r, H, np.full(len(H), kp[0] + kss_noise))
+        except np.linalg.LinAlgError:
+            raise
+        return ll, mu + (0. if mean_new is None else mean_new), var
+
+    def fit(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., want_var=True):
+        self.calls.append('fit')
+        self.kp, self.diag = np.array(kp), diag
+        ll, mu, var = self._one(self.dim, self.x, self.r, diag, kp, xnew, mean_new, kss_noise)
+        return ll, 0., mu, var
+
+    def predict(self, xnew, mean_new=None, kss_noise=0., want_cov=False):
+        kern = _kernel_from_kp(self.dim, self.kp)
+        K = kern(self.x, None, self.diag)
+        H = kern(self.x, xnew)
+        Ki = np.linalg.inv(K)
+        cov = kern(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ Ki @ H.T
+        mu = H @ Ki @ self.r + (0. if mean_new is None else mean_new)
+        return mu, np.diag(cov).copy(), cov if want_cov else None
+
+    def fetch(self, which):
+        K = _kernel_from_kp(self.dim, self.kp)(self.x, None, self.diag)
+        return [K, np.linalg.cholesky(K), np.linalg.inv(K)][which]
+
+    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.,
+                  xnew_per_object=False):
+        self.calls.append('batch_fit:%d' % len(xs))
+        B = len(xs)
+        ll, info = np.zeros(B), np.zeros(B, dtype=np.int32)
+        mu = var = None
+        for b in range(B):
+            grid = None if xnew is None else (np.asarray(xnew)[b] if xnew_per_object else xnew)
+            try:
+                l, m_, v_ = self._one(dim, np.asarray(xs[b], float), np.asarray(resids[b], float),
+                                      None if diags is None else diags[b], kp, grid, mean_new, kss_noise)
+            except np.linalg.LinAlgError:
+                info[b] = 1
+                continue
+            ll[b] = l
+            if m_ is not None:
+                if mu is None:
+                    mu, var = np.zeros((B, len(m_))), np.zeros((B, len(m_)))
+                mu[b], var[b] = m_, v_
+        return ll, info, mu, var

@@ -1,0 +1,115 @@
+"""CPU tests of the host-side mirror (no device calls): scalar preparation, mean function,
+initial guess, lazy lists, sharding helpers -- against the golden vectors / oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import cosmogp_oracle as orc
+import cosmogp_amd
+from cosmogp_amd import kernel as K
+from cosmogp_amd import multigpu
+from cosmogp_amd.gaussian_process import _LazyList
+
+
+def test_kernel_params_match_reference_expressions():
+    h = np.array([0.5, 3.1, 2.2, 1.7])
+    kp = K.kernel_params_2d(h)
+    vi = orc.inv_l_2d(h)
+    assert kp[0] == 1.0 and kp[1] == h[0] ** 2
+    assert np.array_equal(kp[2:], vi.ravel())
+    assert K.kernel_params_2d(h, sigma2_in_train=True)[0] == h[0] ** 2
+    kp1 = K.kernel_params_1d([0.7, 6.5])
+    assert kp1[0] == 0.7 ** 2 and kp1[1] == 0.7 ** 2 and kp1[2] == 6.5 ** 2
+
+
+def test_diag_term_order():
+    e = np.array([0.1, 0.2, 0.3])
+    assert np.array_equal(K.diag_term(3, e, 0.01, 0.03), e ** 2 + 0.01 ** 2 + 0.03 ** 2)
+    assert np.array_equal(K.diag_term(3, None, 0., 0.5), np.full(3, 0.25))
+    assert np.array_equal(K.diag_term(3, e, 0.01, 0.03), orc.diag_noise(3, e, 0.01, 0.03))
+
+
+def test_init_rbf_golden():
+    g = load_golden('init_rbf')
+    xs = [g['x1_%d' % i] for i in range(int(g['n1']))]
+    ys = [g['y1_%d' % i] for i in range(int(g['n1']))]
+    np.testing.assert_allclose(cosmogp_amd.init_rbf(xs, ys), g['guess_1d'], rtol=1e-15)
+    Xs = [g['x2_%d' % i] for i in range(int(g['n2']))]
+    Ys = [g['y2_%d' % i] for i in range(int(g['n2']))]
+    np.testing.assert_allclose(cosmogp_amd.init_rbf(Xs, Ys), g['guess_2d'], rtol=1e-15)
+
+
+def test_constructor_matches_reference_state():
+    g = load_golden('predict_mean_1d_n80')
+    gp = cosmogp_amd.gaussian_process(g['y'], g['x'], y_err=g['e'], Mean_Y=g['mean_y'], Time_mean=g['mean_x'])
+    np.testing.assert_allclose(gp.y0[0], g['y0'], rtol=1e-14)
+    assert gp.N_sn == 1 and gp.nugget == 0. and gp.fit_nugget is False
+    g2 = load_golden('loglik_2d')
+    gp2 = cosmogp_amd.gaussian_process_2d(g2['y'], g2['x'], y_err=g2['e'])
+    np.testing.assert_allclose(gp2.hyperparameters, g2['init_hyp'], rtol=1e-15)
+    with pytest.raises(AssertionError):
+        cosmogp_amd.gaussian_process(g['y'], g['x'], kernel='MATERN')
+    gp3 = cosmogp_amd.gaussian_process(g['y'], g['x'])
+    assert np.array_equal(gp3.y_err[0], np.zeros(80)) and np.array_equal(gp3.y0, np.zeros(1))
+
+
+def test_return_mean_vs_oracle():
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(0, 10, 30))
+    y = np.sin(x)
+    tm = np.linspace(-1, 11, 25)
+    my = np.cos(tm)
+    xn = np.linspace(0, 10, 7)
+    for kw in (dict(), dict(mean_y=my, mean_xaxis=tm), dict(mean_y=my, mean_xaxis=tm, diff=0.3)):
+        np.testing.assert_array_equal(cosmogp_amd.return_mean(y, x, **kw), orc.return_mean(y, x, **kw))
+        np.testing.assert_array_equal(cosmogp_amd.return_mean(y, x, new_x=xn, **kw),
+                                      orc.return_mean(y, x, new_x=xn, **kw))
+    # 2D mean: the reference calls bisplrep(task=1) with no prior task=0 call (mean.py:58-59),
+    # which SciPy 1.15 rejects; the mirror keeps the same call, so both fail the same way.
+    X = rng.uniform(0, 5, (40, 2))
+    Y = np.sin(X[:, 0]) + X[:, 1]
+    g = np.linspace(0, 5, 7)
+    XM = np.array([[a, b] for a in g for b in g])
+    YM = np.sin(XM[:, 0]) + XM[:, 1]
+    for fn in (cosmogp_amd.return_mean, orc.return_mean):
+        with pytest.raises(Exception):
+            fn(Y, X, mean_y=YM, mean_xaxis=XM)
+
+
+def test_svd_inverse_golden():
+    g = load_golden('inverse_n96')
+    inv, ld = cosmogp_amd.svd_inverse(g['K'], return_logdet=True)
+    np.testing.assert_allclose(inv, g['svd_inv'], rtol=0, atol=1e-11 * np.abs(g['svd_inv']).max())
+    assert abs(ld - float(g['svd_logdet'])) <= 1e-12 * abs(ld)
+    inv, ld = cosmogp_amd.svd_inverse(g['K_singular'], return_logdet=True)       # never raises
+    assert abs(ld - float(g['svd_logdet_singular'])) <= 1e-9 * abs(ld)
+
+
+def test_lazy_list():
+    calls = []
+
+    def make(i):
+        calls.append(i)
+        return np.full((2, 2), float(i))
+
+    ll = _LazyList(3, make)
+    assert len(ll) == 3 and calls == []
+    assert ll[1][0, 0] == 1. and ll[1][1, 1] == 1. and calls == [1]
+    assert ll[-1][0, 0] == 2.
+    assert [a[0, 0] for a in ll] == [0., 1., 2.] and sorted(calls) == [0, 1, 2]
+    with pytest.raises(IndexError):
+        ll[3]
+
+
+def test_shard_helpers():
+    for n, w in ((1024, 8), (10, 4), (3, 8), (0, 2)):
+        blocks = [multigpu.shard_bounds(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    costs = np.array([512, 100, 300, 512, 64, 700, 50, 90]) ** 3.
+    parts = multigpu.shard_by_cost(costs, 3)
+    assert sorted(sum(parts, [])) == list(range(8))
+    loads = [costs[p].sum() for p in parts]
+    assert max(loads) <= 700 ** 3. + 1e-9 + min(loads)
