@@ -188,7 +188,7 @@ def main():
         ach = flops / (gemm_ms * 1e-3) / 1e12
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=None,
-                    kernel='k_gemm_nt (v_mfma_f64_16x16x4_f64)', launches_per_fit=int(launches),
+                    kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64)', launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5))
         potrf_ms = st[1] + st[2] + st[3]
         chol_flops = n ** 3 / 3.0

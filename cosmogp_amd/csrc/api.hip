@@ -169,7 +169,7 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     }
     if (tiles * B >= 192) {
         dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2>), g, dim3(256), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4>), g, dim3(512), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta);
     } else {
         nr = rows / 64; nc = cols / 64;

@@ -31,6 +31,17 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction.  Measured on MI355X
+// (tools/microbench_f64.hip, tools/mfma4_layout.hip): 16-17 cycles issue (~30 flop/clk/SIMD,
+// 68 TFLOP/s chip-wide) against ~105 cycles for the 16x16x4 form (~47 TFLOP/s), dependent
+// latency 44 cycles.  Lane maps (probed with unit impulses):
+//   A: lane l holds A_blk[i = l & 3][k = l >> 4],  blk = (l >> 2) & 3
+//   B: lane l holds B_blk[k = l >> 4][j = l & 3]
+//   D: lane l holds D_blk[i = l >> 4][j = l & 3]      (so D_blk is again a B operand of blk)
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -393,13 +404,17 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
 }
 
 // ------------------------------------------------------------------------------------
-// K5: C = beta C + alpha A B^T on v_mfma_f64_16x16x4_f64 -- the trailing SYRK/GEMM update
+// K5: C = beta C + alpha A B^T on v_mfma_f64_4x4x4_4b_f64 -- the trailing SYRK/GEMM update
 // (alpha = -1, beta = 1), the predictive covariance K** - W W^T and the explicit inverse
-// W W^T.  A: rows x K, B: rows x K, both row-major with the same ld and K contiguous, so
-// both operands are fetched the same way.
-//   workgroup = 4 waves in a WM x WN grid, wave tile (TM/WM) x (TN/WN), KB = 16 deep stages
-//   double-buffered in LDS (global -> registers -> LDS, one barrier per stage);
-//   each lane reads 2 consecutive k per ds_read_b128 and uses them in two MFMAs (the k order
+// W W^T.  A: rows x K, B: rows x K, both row-major with the same ld and K contiguous.
+//   workgroup = WM x WN waves, wave tile (TM/WM) x (TN/WN); KB = 16 deep stages double-buffered
+//   in LDS (global -> registers -> LDS, one barrier per stage).
+//   Register tiling for the 4-block instruction: block blk of a wave owns the rows
+//   16 r + 4 blk + (0..3) (r = 0..MT-1: the A fragment is fetched exactly like a 16-row MFMA
+//   operand) and ALL column groups J of the wave tile: the B fragment of group J
+//   (cols 4 J + (l & 3)) is the same in the four blocks, i.e. a broadcast LDS read.
+//   acc[r][J] at lane l = C[16 r + 4 blk + (l >> 4)][4 J + (l & 3)].
+//   Each lane reads 2 consecutive k per ds_read_b128 and uses them in two MFMAs (the k order
 //   inside a stage is permuted identically for A and B, which leaves the sum unchanged).
 //   tri = 1: only tiles on/below the diagonal of the (square-tiled) C region are launched:
 //   tile rows [0, nc) form the triangle, rows [nc, nr) are full.
@@ -408,11 +423,15 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
 #define CGP_KS 18     // LDS row stride (doubles) of a stage: 144 B keeps 16-B alignment
 
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta) {
-    constexpr int MT = TM / WM / 16, NT = TN / WN / 16;
-    constexpr int PA = TM / 32, PB = TN / 32;
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
+    constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
+    constexpr int PA = TM * 8 / NTH, PB = TN * 8 / NTH;   // 16-byte chunks per thread per stage
+    constexpr int RSTEP = NTH / 8;
+    static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) double As[2][TM * CGP_KS];
     __shared__ __attribute__((aligned(16))) double Bs[2][TN * CGP_KS];
     const int bz = blockIdx.z;
@@ -438,26 +457,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 15, lq = lane >> 4;
+    const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
     const double* Ag = A + (long)(ti * TM) * ld;
     const double* Bg = B + (long)(tj * TN) * ld;
-    const int srow = tid >> 3, sch = (tid & 7) * 2;   // staging: 32 rows x 8 chunks of 16 B
+    const int srow = tid >> 3, sch = (tid & 7) * 2;   // staging: RSTEP rows x 8 chunks of 16 B
 
-    d4 acc[MT][NT];
+    double acc[MT][NJ];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (d4){0., 0., 0., 0.};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.;
 
     d2 ra[PA], rb[PB];
 #pragma unroll
-    for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + 32 * p) * ld + sch);
+    for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + sch);
 #pragma unroll
-    for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + 32 * p) * ld + sch);
+    for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + sch);
 #pragma unroll
-    for (int p = 0; p < PA; ++p) *(d2*)(&As[0][(srow + 32 * p) * CGP_KS + sch]) = ra[p];
+    for (int p = 0; p < PA; ++p) *(d2*)(&As[0][(srow + RSTEP * p) * CGP_KS + sch]) = ra[p];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) *(d2*)(&Bs[0][(srow + 32 * p) * CGP_KS + sch]) = rb[p];
+    for (int p = 0; p < PB; ++p) *(d2*)(&Bs[0][(srow + RSTEP * p) * CGP_KS + sch]) = rb[p];
     __syncthreads();
 
     const int nk = K / CGP_KB;
@@ -466,48 +485,53 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(
         if (kt + 1 < nk) {
             const int k1 = (kt + 1) * CGP_KB + sch;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + 32 * p) * ld + k1);
+            for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + k1);
 #pragma unroll
-            for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + 32 * p) * ld + k1);
+            for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + k1);
         }
 #pragma unroll
         for (int t = 0; t < CGP_KB / 8; ++t) {
-            d2 fa[MT], fb[NT];
+            d2 fa[MT], fb[NJ];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 fa[i] = *(const d2*)(&As[cur][(wm * (TM / WM) + i * 16 + lr) * CGP_KS + 8 * t + 2 * lq]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                fb[j] = *(const d2*)(&Bs[cur][(wn * (TN / WN) + j * 16 + lr) * CGP_KS + 8 * t + 2 * lq]);
+            for (int j = 0; j < NJ; ++j)
+                fb[j] = *(const d2*)(&Bs[cur][(wn * (TN / WN) + j * 4 + lp) * CGP_KS + 8 * t + 2 * lq]);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = mfma16(fa[i].x, fb[j].x, acc[i][j]);
-                    acc[i][j] = mfma16(fa[i].y, fb[j].y, acc[i][j]);
-                }
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].x, fb[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].y, fb[j].y, acc[i][j]);
         }
         if (kt + 1 < nk) {
 #pragma unroll
-            for (int p = 0; p < PA; ++p) *(d2*)(&As[cur ^ 1][(srow + 32 * p) * CGP_KS + sch]) = ra[p];
+            for (int p = 0; p < PA; ++p) *(d2*)(&As[cur ^ 1][(srow + RSTEP * p) * CGP_KS + sch]) = ra[p];
 #pragma unroll
-            for (int p = 0; p < PB; ++p) *(d2*)(&Bs[cur ^ 1][(srow + 32 * p) * CGP_KS + sch]) = rb[p];
+            for (int p = 0; p < PB; ++p) *(d2*)(&Bs[cur ^ 1][(srow + RSTEP * p) * CGP_KS + sch]) = rb[p];
         }
         __syncthreads();
     }
 
-    double* Cg = C + (long)(ti * TM + wm * (TM / WM)) * ldc + tj * TN + wn * (TN / WN);
+    // acc[i][j] at lane l = C[16 i + 4 blk + (l >> 4)][4 j + (l & 3)],  blk = (l >> 2) & 3
+    double* Cg = C + (long)(ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq) * ldc + tj * TN + wn * (TN / WN) + lp;
+    if (beta != 0.) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* p = Cg + (long)(i * 16 + lq + 4 * r) * ldc + j * 16 + lr;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.) v += beta * (*p);
-                *p = v;
+            for (int j = 0; j < NJ; ++j) {
+                double* p = Cg + (long)(i * 16) * ldc + j * 4;
+                *p = alpha * acc[i][j] + beta * (*p);
             }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) Cg[(long)(i * 16) * ldc + j * 4] = alpha * acc[i][j];
+    }
 }
 
 // ------------------------------------------------------------------------------------
