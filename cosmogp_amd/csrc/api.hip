@@ -13,7 +13,16 @@
 namespace {
 
 constexpr int NB = CGP_NB;
-constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 4) * sizeof(double);
+#ifndef GEMM_BIG_TILE_THRESHOLD
+#define GEMM_BIG_TILE_THRESHOLD 1000000000L
+#endif
+#ifndef GEMM_KB_BIG
+#define GEMM_KB_BIG 16
+#endif
+#ifndef GEMM_KB_SMALL
+#define GEMM_KB_SMALL 16
+#endif
+constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144 + 4 * 16 * CGP_XLD) * sizeof(double);
 
 inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
 
@@ -167,15 +176,15 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
         h->gemm_flops += 2.0 * K * elems * B;
     }
-    if (tiles * B >= 192) {
+    if (tiles * B >= GEMM_BIG_TILE_THRESHOLD) {
         dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4>), g, dim3(512), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 4, 4, GEMM_KB_BIG>), g, dim3(1024), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta);
     } else {
         nr = rows / 64; nc = cols / 64;
         tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
         dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<64, 64, 2, 2>), g, dim3(256), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<64, 64, 2, 2, GEMM_KB_SMALL>), g, dim3(256), 0, h->stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta);
     }
     HIPCHK(hipGetLastError());
@@ -193,7 +202,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
         const int blk = (int)(c0 / NB);
         if (chol) {
             StageScope sc(h, ST_POTRF);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, P.B), dim3(256), LEAF_LDS, h->stream, P.M, ld, P.sM, (int)c0,
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, P.B), dim3(CGP_K3_THREADS), LEAF_LDS, h->stream, P.M, ld, P.sM, (int)c0,
                                P.wsW, P.sW, P.ldp, P.sLd, P.info, blk);
             HIPCHK(hipGetLastError());
         }

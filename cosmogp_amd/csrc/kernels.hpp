@@ -10,12 +10,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define CGP_NB 128          // leaf block of the Cholesky (diagonal block lives in LDS)
 #define CGP_SB 16           // sub-block inside the leaf = MFMA tile edge
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// In-kernel phase stamps: diagnostic builds only (tools/leaf_stamps.hip defines CGP_STAMPS).
+#ifdef CGP_STAMPS
+__device__ unsigned long long g_stamps[256];
+#define CGP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[i] = t_; } } while (0)
+#else
+#define CGP_STAMP(i) do {} while (0)
+#endif
 
 struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.h
     double amp_train, amp_cross, p0, p1, p2, p3;
@@ -41,6 +51,11 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
+
+// Same-wave LDS hand-off (one lane writes, other lanes of the SAME wave read): the LDS pipe is
+// in order per wave, so no barrier is needed, but the compiler must not reorder the accesses
+// (stores as double and loads as d2 do not alias for its type-based analysis).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -212,39 +227,98 @@ __global__ void k_pad_square(const double* __restrict__ src, long lds, double* _
 //   8 sub-steps of 16 columns:
 //   (a) wave 0 factors the 16 x 16 diagonal sub-block T in registers: lane r < 16 owns row r;
 //       lanes 16..31 carry the rows of the identity through the same elimination and end up
-//       holding T^-T (the "tall" trick at register level); pivots travel by v_readlane.
-//   (c) sub-panel below T: P = A_sub * T^-T on the MFMA (4 x 16x16x4 per 16-row tile)
-//   (e) trailing update inside the block: C -= P_i P_j^T on the MFMA
+//       holding T^-T (the "tall" trick at register level); pivots travel by v_readlane;
+//       1/sqrt(pivot) is v_rsq_f64 + two Goldschmidt steps (a dependent chain of ~10 FMAs
+//       instead of the ~60 instructions of an IEEE sqrt followed by an IEEE divide).
+//   (c) sub-panel below T: P = A_sub * T^-T          (4-block MFMA, 16 instructions per tile)
+//   (e) trailing update inside the block: C -= P_i P_j^T   (same)
 // Outputs: L (lower, in place in HBM), the eight T^-T blocks (for the panel solve K4),
 // sum(2 log L_ii) for the log-determinant, and LAPACK-style info.
 // ------------------------------------------------------------------------------------
-#define CGP_LDA 130   // LDS row stride in doubles: 16 rows x 4 k-groups hit 64 distinct banks
+#define CGP_LDA 130   // LDS row stride in doubles (1040 B: rows stay 16-B aligned)
 
-__global__ __launch_bounds__(256) void k_potrf_diag(
+// sd = sqrt(d), rs = 1/sqrt(d) to ~1 ulp (no range scaling: pivots of a covariance matrix are O(1))
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& sd, double& rs) {
+    double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double e = __builtin_fma(-g, g, d);
+    sd = __builtin_fma(e, h, g);
+    rs = h + h;
+}
+
+// one 16x16 tile product on the 4-block MFMA: acc[J] (+)= sum_k A[row][k] * B[4J+u][k], k = 0..15.
+// Arow points at A[16-row tile][k0] (row stride CGP_LDA), lane supplies its own row (l & 15);
+// Brow points at B[16-col tile][k0].  NEG negates A.  Lane fields: u = l&3, q = l>>4.
+template <bool NEG>
+__device__ __forceinline__ void tile_mma_nt(double (&acc)[4], const double* Arow, const double* Brow,
+                                            int lr, int u, int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        d2 a = *(const d2*)(Arow + lr * CGP_LDA + 8 * t + 2 * q);
+        if (NEG) a = -a;
+        d2 b[4];
+#pragma unroll
+        for (int J = 0; J < 4; ++J) b[J] = *(const d2*)(Brow + (4 * J + u) * CGP_LDA + 8 * t + 2 * q);
+#pragma unroll
+        for (int J = 0; J < 4; ++J) acc[J] = mfma4(a.x, b[J].x, acc[J]);
+#pragma unroll
+        for (int J = 0; J < 4; ++J) acc[J] = mfma4(a.y, b[J].y, acc[J]);
+    }
+}
+
+#define CGP_K3_THREADS 512
+#define CGP_K3_WAVES (CGP_K3_THREADS / 64)
+
+__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
     double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                          // [128][CGP_LDA]
     double* Ws = smem + CGP_NB * CGP_LDA;       // [8][16][16]  T^-T blocks (upper triangular)
+    double* Lc = Ws + 8 * 256;                  // [2][64] column broadcast buffer of phase (a)
     const int b = blockIdx.z;
     M += (long)b * sM + (long)c0 * ld + c0;
     wsW += (long)b * sW + (long)blk * (8 * 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
+    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
 
-    for (int idx = tid; idx < CGP_NB * (CGP_NB / 2); idx += 256) {
-        int r = idx >> 6, c = (idx & 63) * 2;
-        d2 v = *(const d2*)(M + (long)r * ld + c);
-        As[r * CGP_LDA + c] = v.x;
-        As[r * CGP_LDA + c + 1] = v.y;
+    CGP_STAMP(0);
+    // load the tiles on/below the block diagonal: all loads first (8 x 16 B in flight per thread)
+    {
+        constexpr int NCH = CGP_NB * (CGP_NB / 2) / CGP_K3_THREADS;
+        d2 tmp[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int idx = tid + k * CGP_K3_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            tmp[k] = (d2){0., 0.};
+            if ((c >> 4) <= (r >> 4)) tmp[k] = *(const d2*)(M + (long)r * ld + c);
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int idx = tid + k * CGP_K3_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            if ((c >> 4) <= (r >> 4)) *(d2*)(As + r * CGP_LDA + c) = tmp[k];
+        }
     }
     __syncthreads();
+    CGP_STAMP(1);
 
     int bad = 0;   // 1-based local index of the first non-positive pivot (wave 0 only)
     for (int s = 0; s < 8; ++s) {
         const int o = s * 16;
+        CGP_STAMP(2 + 4 * s);
         if (wave == 0) {
-            double v[16];
+            // lanes 0..15: rows of T; lanes 16..31: rows of the identity (-> T^-T); others idle.
+            // Column j: pivot by readlane, 1/sqrt by rsq + Goldschmidt, column j+1 is updated at
+            // once through readlane (it is on the critical chain), columns >= j+2 one step later
+            // from an LDS broadcast of the scaled column (fills the latency of the next chain).
+            double v[16], lprev = 0.;
+            d2 bc[8];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 double t = 0.;
@@ -256,16 +330,29 @@ __global__ __launch_bounds__(256) void k_potrf_diag(
             for (int j = 0; j < 16; ++j) {
                 const double d = readlane_f64(v[j], j);
                 if (!(d > 0.) && bad == 0) bad = o + j + 1;
-                const double sd = sqrt(d);
-                const double rs = 1.0 / sd;
+                double sd, rs;
+                sqrt_rsqrt(d, sd, rs);
                 double l = v[j] * rs;
                 if (lane == j) l = sd;
                 v[j] = l;
+                if (j > 0) {       // delayed updates of column j-1 on columns >= j+1
 #pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    const double lc = readlane_f64(l, c);
-                    v[c] = __builtin_fma(-l, lc, v[c]);
+                    for (int c = j + 1; c < 16; ++c) {
+                        const double lc = (c & 1) ? bc[c >> 1].y : bc[c >> 1].x;
+                        v[c] = __builtin_fma(-lprev, lc, v[c]);
+                    }
                 }
+                if (j < 15) {
+                    const double lc = readlane_f64(l, j + 1);
+                    v[j + 1] = __builtin_fma(-l, lc, v[j + 1]);
+                }
+                if (j < 14) {
+                    Lc[(j & 1) * 64 + lane] = l;          // every lane writes (no exec-mask branch)
+                    wave_lds_fence();
+#pragma unroll
+                    for (int c2 = (j + 2) >> 1; c2 < 8; ++c2) bc[c2] = *(const d2*)(Lc + (j & 1) * 64 + 2 * c2);
+                }
+                lprev = l;
             }
             if (lane < 16) {
 #pragma unroll
@@ -276,131 +363,185 @@ __global__ __launch_bounds__(256) void k_potrf_diag(
             }
         }
         __syncthreads();
-        // (c) sub-panel rows below T:  P[ti] = A[ti][s] * T^-T
-        for (int ti = s + 1 + wave; ti < 8; ti += 4) {
-            d4 acc = {0., 0., 0., 0.};
-            double a[4], bb[4];
+        CGP_STAMP(3 + 4 * s);
+        // (c) sub-panel rows below T:  P[ti] = A[ti][s] * T^-T   (B[k][n] = Ws[s][k][n])
+        for (int ti = s + 1 + wave; ti < 8; ti += CGP_K3_WAVES) {
+            double acc[4] = {0., 0., 0., 0.};
+            const double* Arow = As + (ti * 16) * CGP_LDA + o;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                a[kk] = As[(ti * 16 + lr) * CGP_LDA + o + lq + 4 * kk];
-                bb[kk] = Ws[s * 256 + (lq + 4 * kk) * 16 + lr];
+            for (int t = 0; t < 2; ++t) {
+                d2 a = *(const d2*)(Arow + lr * CGP_LDA + 8 * t + 2 * lq);
+                double b0[4], b1[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    b0[J] = Ws[s * 256 + (8 * t + 2 * lq) * 16 + 4 * J + lu];
+                    b1[J] = Ws[s * 256 + (8 * t + 2 * lq + 1) * 16 + 4 * J + lu];
+                }
+#pragma unroll
+                for (int J = 0; J < 4; ++J) acc[J] = mfma4(a.x, b0[J], acc[J]);
+#pragma unroll
+                for (int J = 0; J < 4; ++J) acc[J] = mfma4(a.y, b1[J], acc[J]);
             }
+            // acc[J] at lane (u, blk, q) = P[16 ti + 4 blk + q][4 J + u]
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = mfma16(a[kk], bb[kk], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) As[(ti * 16 + lq + 4 * r) * CGP_LDA + o + lr] = acc[r];
+            for (int J = 0; J < 4; ++J) As[(ti * 16 + 4 * lb + lq) * CGP_LDA + o + 4 * J + lu] = acc[J];
         }
         __syncthreads();
+        CGP_STAMP(4 + 4 * s);
         // (e) trailing tiles (ti >= tj > s):  C[ti][tj] -= P[ti] P[tj]^T
         {
-            const int w = 7 - s;              // remaining tile rows/cols
+            const int w = 7 - s;
             const int ntile = w * (w + 1) / 2;
-            for (int t = wave; t < ntile; t += 4) {
+            for (int t = wave; t < ntile; t += CGP_K3_WAVES) {
                 int i = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
                 while ((i + 1) * (i + 2) / 2 <= t) ++i;
                 while (i * (i + 1) / 2 > t) --i;
                 const int j = t - i * (i + 1) / 2;
                 const int ti = s + 1 + i, tj = s + 1 + j;
-                d4 acc;
+                double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
+                double acc[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = As[(ti * 16 + lq + 4 * r) * CGP_LDA + tj * 16 + lr];
-                double a[4], bb[4];
+                for (int J = 0; J < 4; ++J) acc[J] = Ct[4 * J];
+                tile_mma_nt<true>(acc, As + (ti * 16) * CGP_LDA + o, As + (tj * 16) * CGP_LDA + o, lr, lu, lq);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    a[kk] = -As[(ti * 16 + lr) * CGP_LDA + o + lq + 4 * kk];
-                    bb[kk] = As[(tj * 16 + lr) * CGP_LDA + o + lq + 4 * kk];
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = mfma16(a[kk], bb[kk], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) As[(ti * 16 + lq + 4 * r) * CGP_LDA + tj * 16 + lr] = acc[r];
+                for (int J = 0; J < 4; ++J) Ct[4 * J] = acc[J];
             }
         }
         __syncthreads();
     }
 
+    CGP_STAMP(40);
     // write L back (tiles on and below the block diagonal), T^-T blocks, logdet, info
-    for (int idx = tid; idx < CGP_NB * CGP_NB; idx += 256) {
-        int r = idx >> 7, c = idx & 127;
-        if ((c >> 4) <= (r >> 4)) M[(long)r * ld + c] = As[r * CGP_LDA + c];
+    {
+        constexpr int NCH = CGP_NB * (CGP_NB / 2) / CGP_K3_THREADS;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int idx = tid + k * CGP_K3_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            if ((c >> 4) <= (r >> 4)) *(d2*)(M + (long)r * ld + c) = *(const d2*)(As + r * CGP_LDA + c);
+        }
     }
-    for (int idx = tid; idx < 8 * 256; idx += 256) wsW[idx] = Ws[idx];
+    for (int idx = tid; idx < 8 * 256; idx += CGP_K3_THREADS) wsW[idx] = Ws[idx];
     double lg = 0.;
     if (tid < CGP_NB) lg = 2. * log(As[tid * CGP_LDA + tid]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
-    double* red = smem + CGP_NB * CGP_LDA + 8 * 256;   // 4 doubles after Ws (all LDS dynamic)
-    if (lane == 0) red[wave] = lg;
+    double* red = Lc + 128;                     // 2 doubles after the broadcast buffer
+    if (lane == 0 && wave < 2) red[wave] = lg;
     __syncthreads();
     if (tid == 0) {
         logdet_parts[(long)b * sLd + blk] = red[0] + red[1];
         if (bad != 0 && info[b] == 0) info[b] = c0 + bad;
     }
+    CGP_STAMP(41);
 }
 
 // ------------------------------------------------------------------------------------
-// K4: panel solve  X = A L_kk^-T  for the rows below a diagonal block, by block forward
-// substitution on the transposed problem X^T = L_kk^-1 A^T.  One wave owns 16 panel rows
-// and keeps all of X^T (8 tiles) in registers: because the f64 MFMA result layout equals
-// its B-operand layout, every step  X_j^T = T_j^-1 (A_j^T - sum_{p<j} L_jp X_p^T)  chains
-// register to register; L_kk (from HBM, just written by K3) is staged in LDS once per
-// workgroup, T_j^-T blocks come from K3's workspace.
+// K4: panel solve  X = A L_kk^-T  for the rows below a diagonal block (right-looking over the
+// eight 16-column tiles): X_j = S_j T_j^-T, then S_i -= X_j L_ij^T for i > j.
+// One wave owns 16 panel rows; S (8 tiles) lives in registers in the 4-block MFMA result
+// layout; a finished X_j goes through a wave-private LDS tile to be re-read as an A operand.
+// L_kk (strictly lower 16x16 tiles) and the T_j^-T blocks are staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------
+#define CGP_XLD 18    // row stride of the wave-private X tile (16 x 16 doubles, padded)
+
 __global__ __launch_bounds__(256) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
     long sW, int blk) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ls = smem;                          // [128][CGP_LDA] lower part used
-    double* Ws = smem + CGP_NB * CGP_LDA;       // [8][16][16]
+    double* Ls = smem;                               // [128][CGP_LDA] strictly-lower tiles used
+    double* Ws = smem + CGP_NB * CGP_LDA;            // [8][16][16]
     const int b = blockIdx.z;
     M += (long)b * sM;
     wsW += (long)b * sW + (long)blk * (8 * 256);
     const double* Lg = M + (long)c0 * ld + c0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4;
-    double* Ap = M + (long)(r0 + blockIdx.x * 64 + wave * 16) * ld + c0;
+    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+    double* Xs = smem + CGP_NB * CGP_LDA + 8 * 256 + 144 + wave * (16 * CGP_XLD);   // wave-private
+    double* Ap = M + (long)(r0 + blockIdx.x * 64 + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
 
-    // prefetch this wave's A^T tiles in C/D layout: S[jb][r] = A[row lr][16 jb + lq + 4 r]
-    d4 S[8];
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[jb][r] = Ap[(long)lr * ld + jb * 16 + lq + 4 * r];
-
-    for (int idx = tid; idx < CGP_NB * (CGP_NB / 2); idx += 256) {
-        int r = idx >> 6, c = (idx & 63) * 2;
-        if ((c >> 4) < (r >> 4)) {          // strictly-lower 16x16 tiles only
-            d2 v = *(const d2*)(Lg + (long)r * ld + c);
-            Ls[r * CGP_LDA + c] = v.x;
-            Ls[r * CGP_LDA + c + 1] = v.y;
-        }
-    }
-    for (int idx = tid; idx < 8 * 256; idx += 256) Ws[idx] = wsW[idx];
-    __syncthreads();
-
-    d4 X[8];
+    CGP_STAMP(50);
+    // This wave's 16 x 128 panel rows in MFMA result layout.  The column slot (J, u) of a 16-wide
+    // tile stands for column 4 u + J (any fixed permutation is legal as long as the B operands use
+    // the same one), so a lane's four J values are 4 contiguous doubles: 16-byte loads/stores.
+    double S[8][4];
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {
-        d4 acc = S[jb];
+        d2 t0 = *(const d2*)(Ap + jb * 16), t1 = *(const d2*)(Ap + jb * 16 + 2);
+        S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
+    }
+    // L_kk strictly-lower tiles -> LDS (all loads of a batch in flight before the LDS writes)
 #pragma unroll
-        for (int p = 0; p < jb; ++p) {
+    for (int batch = 0; batch < 4; ++batch) {
+        d2 tmp[8];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double a = -Ls[(jb * 16 + lr) * CGP_LDA + p * 16 + lq + 4 * kk];
-                acc = mfma16(a, X[p][kk], acc);
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + (batch * 8 + k) * 256, r = idx >> 6, c = (idx & 63) * 2;
+            tmp[k] = (d2){0., 0.};
+            if ((c >> 4) < (r >> 4)) tmp[k] = *(const d2*)(Lg + (long)r * ld + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + (batch * 8 + k) * 256, r = idx >> 6, c = (idx & 63) * 2;
+            if ((c >> 4) < (r >> 4)) *(d2*)(Ls + r * CGP_LDA + c) = tmp[k];
+        }
+    }
+    {
+        d2 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = *(const d2*)(wsW + 2 * (tid + k * 256));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(d2*)(Ws + 2 * (tid + k * 256)) = w[k];
+    }
+    __syncthreads();
+    CGP_STAMP(51);
+
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        CGP_STAMP(52 + jb);
+        wave_lds_fence();
+        // S_jb -> LDS (result layout) -> A operand;  X_jb = S_jb * T_jb^-T
+        *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu) = (d2){S[jb][0], S[jb][1]};
+        *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu + 2) = (d2){S[jb][2], S[jb][3]};
+        wave_lds_fence();
+        double x[4] = {0., 0., 0., 0.};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            d2 a = *(const d2*)(Xs + lr * CGP_XLD + 8 * t + 2 * lq);
+            const double* w0 = Ws + jb * 256 + (8 * t + 2 * lq) * 16 + 4 * lu;     // B[k][4u + J]
+            d2 p0 = *(const d2*)(w0), p1 = *(const d2*)(w0 + 2), p2 = *(const d2*)(w0 + 16), p3 = *(const d2*)(w0 + 18);
+            x[0] = mfma4(a.x, p0.x, x[0]); x[1] = mfma4(a.x, p0.y, x[1]);
+            x[2] = mfma4(a.x, p1.x, x[2]); x[3] = mfma4(a.x, p1.y, x[3]);
+            x[0] = mfma4(a.y, p2.x, x[0]); x[1] = mfma4(a.y, p2.y, x[1]);
+            x[2] = mfma4(a.y, p3.x, x[2]); x[3] = mfma4(a.y, p3.y, x[3]);
+        }
+        *(d2*)(Ap + jb * 16) = (d2){x[0], x[1]};
+        *(d2*)(Ap + jb * 16 + 2) = (d2){x[2], x[3]};
+        if (jb < 7) {
+            wave_lds_fence();
+            *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu) = (d2){x[0], x[1]};
+            *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu + 2) = (d2){x[2], x[3]};
+            wave_lds_fence();
+            // S_i -= X_jb * L[i][jb]^T  for every later tile i  (B row of slot (J,u) = 16 i + 4 u + J)
+            d2 a[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = -*(const d2*)(Xs + lr * CGP_XLD + 8 * t + 2 * lq);
+#pragma unroll
+            for (int i = jb + 1; i < 8; ++i) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    d2 bb[4];
+#pragma unroll
+                    for (int J = 0; J < 4; ++J)
+                        bb[J] = *(const d2*)(Ls + (i * 16 + 4 * lu + J) * CGP_LDA + jb * 16 + 8 * t + 2 * lq);
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) S[i][J] = mfma4(a[t].x, bb[J].x, S[i][J]);
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) S[i][J] = mfma4(a[t].y, bb[J].y, S[i][J]);
+                }
             }
         }
-        d4 y = {0., 0., 0., 0.};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            // T_j^-1[a][k] = (T_j^-T)[k][a]
-            double a = Ws[jb * 256 + (lq + 4 * kk) * 16 + lr];
-            y = mfma16(a, acc[kk], y);
-        }
-        X[jb] = y;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ap[(long)lr * ld + jb * 16 + lq + 4 * r] = y[r];
     }
+    CGP_STAMP(60);
 }
 
 // ------------------------------------------------------------------------------------
@@ -419,21 +560,23 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
 //   tri = 1: only tiles on/below the diagonal of the (square-tiled) C region are launched:
 //   tile rows [0, nc) form the triangle, rows [nc, nr) are full.
 // ------------------------------------------------------------------------------------
-#define CGP_KB 16
-#define CGP_KS 18     // LDS row stride (doubles) of a stage: 144 B keeps 16-B alignment
-
-template <int TM, int TN, int WM, int WN>
+// KB = stage depth (16 or 32); LDS row stride KB + 2 doubles keeps every row 16-B aligned
+// ABLATE (diagnostic builds only, tools/gemm_ablate.hip): 1 = no global loads inside the loop,
+// 2 = additionally no LDS fragment reads inside the loop (wrong results, timing only)
+template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
-    constexpr int PA = TM * 8 / NTH, PB = TN * 8 / NTH;   // 16-byte chunks per thread per stage
-    constexpr int RSTEP = NTH / 8;
+    constexpr int KS = KB + 2;
+    constexpr int CPR = KB / 2;               // 16-byte chunks per row of a stage
+    constexpr int PA = TM * CPR / NTH, PB = TN * CPR / NTH;   // chunks per thread per stage
+    constexpr int RSTEP = NTH / CPR;
     static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
-    __shared__ __attribute__((aligned(16))) double As[2][TM * CGP_KS];
-    __shared__ __attribute__((aligned(16))) double Bs[2][TN * CGP_KS];
+    __shared__ __attribute__((aligned(16))) double As[2][TM * KS];
+    __shared__ __attribute__((aligned(16))) double Bs[2][TN * KS];
     const int bz = blockIdx.z;
     C += (long)bz * sC;
     A += (long)bz * sAB;
@@ -460,7 +603,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
     const double* Ag = A + (long)(ti * TM) * ld;
     const double* Bg = B + (long)(tj * TN) * ld;
-    const int srow = tid >> 3, sch = (tid & 7) * 2;   // staging: RSTEP rows x 8 chunks of 16 B
+    const int srow = tid / CPR, sch = (tid % CPR) * 2;   // staging: RSTEP rows x CPR chunks of 16 B
 
     double acc[MT][NJ];
 #pragma unroll
@@ -468,36 +611,43 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.;
 
-    d2 ra[PA], rb[PB];
+    // Global -> registers two stages ahead, registers -> LDS one stage ahead: a load has two
+    // full stages of MFMA work to land (thin K = 128 updates are otherwise latency-bound).
+    d2 ra[2][PA], rb[2][PB];
+    const int nk = K / KB;
+    auto gload = [&](auto par, int kt) {
+        constexpr int P = decltype(par)::value;
+        const int k1 = kt * KB + sch;
 #pragma unroll
-    for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + sch);
+        for (int p = 0; p < PA; ++p) ra[P][p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + k1);
 #pragma unroll
-    for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + sch);
+        for (int p = 0; p < PB; ++p) rb[P][p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + k1);
+    };
+    auto lstore = [&](auto par, int buf) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
-    for (int p = 0; p < PA; ++p) *(d2*)(&As[0][(srow + RSTEP * p) * CGP_KS + sch]) = ra[p];
+        for (int p = 0; p < PA; ++p) *(d2*)(&As[buf][(srow + RSTEP * p) * KS + sch]) = ra[P][p];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) *(d2*)(&Bs[0][(srow + RSTEP * p) * CGP_KS + sch]) = rb[p];
-    __syncthreads();
-
-    const int nk = K / CGP_KB;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k1 = (kt + 1) * CGP_KB + sch;
+        for (int p = 0; p < PB; ++p) *(d2*)(&Bs[buf][(srow + RSTEP * p) * KS + sch]) = rb[P][p];
+    };
+    auto compute = [&](int cur, int kt) {
+        d2 fa[MT], fb[NJ];
+        if (ABLATE >= 2) {
 #pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + k1);
+            for (int i = 0; i < MT; ++i) fa[i] = ra[0][0] + (double)(i + kt);
 #pragma unroll
-            for (int p = 0; p < PB; ++p) rb[p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + k1);
+            for (int j = 0; j < NJ; ++j) fb[j] = rb[0][0] + (double)(j - kt);
         }
 #pragma unroll
-        for (int t = 0; t < CGP_KB / 8; ++t) {
-            d2 fa[MT], fb[NJ];
+        for (int t = 0; t < KB / 8; ++t) {
+            if (ABLATE < 2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = *(const d2*)(&As[cur][(wm * (TM / WM) + i * 16 + lr) * CGP_KS + 8 * t + 2 * lq]);
+                for (int i = 0; i < MT; ++i)
+                    fa[i] = *(const d2*)(&As[cur][(wm * (TM / WM) + i * 16 + lr) * KS + 8 * t + 2 * lq]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                fb[j] = *(const d2*)(&Bs[cur][(wn * (TN / WN) + j * 4 + lp) * CGP_KS + 8 * t + 2 * lq]);
+                for (int j = 0; j < NJ; ++j)
+                    fb[j] = *(const d2*)(&Bs[cur][(wn * (TN / WN) + j * 4 + lp) * KS + 8 * t + 2 * lq]);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -507,13 +657,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].y, fb[j].y, acc[i][j]);
         }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) *(d2*)(&As[cur ^ 1][(srow + RSTEP * p) * CGP_KS + sch]) = ra[p];
-#pragma unroll
-            for (int p = 0; p < PB; ++p) *(d2*)(&Bs[cur ^ 1][(srow + RSTEP * p) * CGP_KS + sch]) = rb[p];
-        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    gload(P0{}, 0);
+    if (nk > 1) gload(P1{}, 1);
+    lstore(P0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even stage kt: registers P1 hold stage kt+1, P0 is free
+        if (ABLATE == 0 && kt + 2 < nk) gload(P0{}, kt + 2);
+        compute(0, kt);
+        if (kt + 1 < nk) lstore(P1{}, 1);
         __syncthreads();
+        if (kt + 1 < nk) {
+            // odd stage kt+1: registers P0 hold stage kt+2, P1 is free
+            if (ABLATE == 0 && kt + 3 < nk) gload(P1{}, kt + 3);
+            compute(1, kt + 1);
+            if (kt + 2 < nk) lstore(P0{}, 0);
+            __syncthreads();
+        }
     }
 
     // acc[i][j] at lane l = C[16 i + 4 blk + (l >> 4)][4 j + (l & 3)],  blk = (l >> 2) & 3
