@@ -237,19 +237,19 @@ __global__ void k_pad_square(const double* __restrict__ src, long lds, double* _
 // ------------------------------------------------------------------------------------
 #define CGP_LDA 130   // LDS row stride in doubles (1040 B: rows stay 16-B aligned)
 
-// sd = sqrt(d), rs = 1/sqrt(d) to ~1 ulp (no range scaling: pivots of a covariance matrix are O(1))
-__device__ __forceinline__ void sqrt_rsqrt(double d, double& sd, double& rs) {
-    double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double e = __builtin_fma(-g, g, d);
-    sd = __builtin_fma(e, h, g);
-    rs = h + h;
+// Pivot arithmetic of the elimination.  Measured dependent latencies of fp64 VALU ops on gfx950
+// (tools/lat_f64.hip): v_fma_f64 32, v_mul/v_add_f64 44, v_rsq_f64 ~52, v_readlane pair + use ~56
+// cycles, so the pivot chain is written for minimum DEPTH: y = rsq(d) is refined in one shot,
+//   1/sqrt(d) = y (1 + e/2 + 3 e^2/8 + 5 e^3/16),  e = 1 - d y^2   (error O(e^4)),
+// applied directly to the column value:  l = v y + (v y e) p.
+__device__ __forceinline__ void pivot_scale(double d, double v, double& l, double& sd) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double t = d * y;                 // ~ sqrt(d)
+    const double vy = v * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double p = __builtin_fma(__builtin_fma(0.3125, e, 0.375), e, 0.5);
+    l = __builtin_fma(vy * e, p, vy);
+    sd = __builtin_fma(t * e, p, t);        // off the chain: only stored
 }
 
 // one 16x16 tile product on the 4-block MFMA: acc[J] (+)= sum_k A[row][k] * B[4J+u][k], k = 0..15.
@@ -309,15 +309,36 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     CGP_STAMP(1);
 
     int bad = 0;   // 1-based local index of the first non-positive pivot (wave 0 only)
+    int pending_s = -1;
     for (int s = 0; s < 8; ++s) {
         const int o = s * 16;
         CGP_STAMP(2 + 4 * s);
+        if (wave != 0 && pending_s >= 0) {
+            // (e2) of sub-step pending_s: tiles (ti >= tj >= pending_s + 2), waves 1..
+            const int ps = pending_s, po = ps * 16;
+            const int w = 6 - ps;                       // tile rows/cols left after column ps+1
+            const int ntile = w * (w + 1) / 2;
+            for (int t = wave - 1; t < ntile; t += CGP_K3_WAVES - 1) {
+                int i = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                while (i * (i + 1) / 2 > t) --i;
+                const int j = t - i * (i + 1) / 2;
+                const int ti = ps + 2 + i, tj = ps + 2 + j;
+                double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
+                double acc[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) acc[J] = Ct[4 * J];
+                tile_mma_nt<true>(acc, As + (ti * 16) * CGP_LDA + po, As + (tj * 16) * CGP_LDA + po, lr, lu, lq);
+#pragma unroll
+                for (int J = 0; J < 4; ++J) Ct[4 * J] = acc[J];
+            }
+        }
         if (wave == 0) {
             // lanes 0..15: rows of T; lanes 16..31: rows of the identity (-> T^-T); others idle.
             // Column j: pivot by readlane, 1/sqrt by rsq + Goldschmidt, column j+1 is updated at
             // once through readlane (it is on the critical chain), columns >= j+2 one step later
             // from an LDS broadcast of the scaled column (fills the latency of the next chain).
-            double v[16], lprev = 0.;
+            double v[16], lprev = 0., pv;
             d2 bc[8];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -326,15 +347,15 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
                 else if (lane < 32) t = (c == lane - 16) ? 1. : 0.;
                 v[c] = t;
             }
+            pv = v[0];
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double d = readlane_f64(v[j], j);
+                const double d = readlane_f64(pv, j);
                 if (!(d > 0.) && bad == 0) bad = o + j + 1;
-                double sd, rs;
-                sqrt_rsqrt(d, sd, rs);
-                double l = v[j] * rs;
-                if (lane == j) l = sd;
-                v[j] = l;
+                double l, sd;
+                pivot_scale(d, v[j], l, sd);             // lane j's own l is never used as a multiplier
+                v[j] = (lane == j) ? sd : l;
                 if (j > 0) {       // delayed updates of column j-1 on columns >= j+1
 #pragma unroll
                     for (int c = j + 1; c < 16; ++c) {
@@ -343,6 +364,8 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
                     }
                 }
                 if (j < 15) {
+                    // next pivot straight from the pivot lane's own v - l^2 (no readlane on the chain)
+                    pv = __builtin_fma(-l, l, v[j + 1]);
                     const double lc = readlane_f64(l, j + 1);
                     v[j + 1] = __builtin_fma(-l, lc, v[j + 1]);
                 }
@@ -354,6 +377,7 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
                 }
                 lprev = l;
             }
+            __builtin_amdgcn_s_setprio(0);
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) As[(o + lane) * CGP_LDA + o + c] = (c <= lane) ? v[c] : 0.;
@@ -388,26 +412,22 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
         }
         __syncthreads();
         CGP_STAMP(4 + 4 * s);
-        // (e) trailing tiles (ti >= tj > s):  C[ti][tj] -= P[ti] P[tj]^T
-        {
-            const int w = 7 - s;
-            const int ntile = w * (w + 1) / 2;
-            for (int t = wave; t < ntile; t += CGP_K3_WAVES) {
-                int i = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
-                while ((i + 1) * (i + 2) / 2 <= t) ++i;
-                while (i * (i + 1) / 2 > t) --i;
-                const int j = t - i * (i + 1) / 2;
-                const int ti = s + 1 + i, tj = s + 1 + j;
-                double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
-                double acc[4];
+        // (e) trailing tiles (ti >= tj > s):  C[ti][tj] -= P[ti] P[tj]^T, in two parts so that the
+        // next pivot block overlaps the bulk of it (look-ahead inside the leaf):
+        //   (e1) tile column s+1 (what phase (a) of s+1 and its sub-panel need), all waves;
+        //   (e2) tile columns >= s+2, by waves 1.. while wave 0 already runs phase (a) of s+1.
+        for (int ti = s + 1 + wave; ti < 8; ti += CGP_K3_WAVES) {
+            const int tj = s + 1;
+            double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
+            double acc[4];
 #pragma unroll
-                for (int J = 0; J < 4; ++J) acc[J] = Ct[4 * J];
-                tile_mma_nt<true>(acc, As + (ti * 16) * CGP_LDA + o, As + (tj * 16) * CGP_LDA + o, lr, lu, lq);
+            for (int J = 0; J < 4; ++J) acc[J] = Ct[4 * J];
+            tile_mma_nt<true>(acc, As + (ti * 16) * CGP_LDA + o, As + (tj * 16) * CGP_LDA + o, lr, lu, lq);
 #pragma unroll
-                for (int J = 0; J < 4; ++J) Ct[4 * J] = acc[J];
-            }
+            for (int J = 0; J < 4; ++J) Ct[4 * J] = acc[J];
         }
         __syncthreads();
+        pending_s = s;        // (e2) of this sub-step is done at the top of the next iteration
     }
 
     CGP_STAMP(40);
