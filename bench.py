@@ -69,6 +69,20 @@ def make_workload(name, rank=0):
         return dict(dim=1, n=n, m=m, B=B, xs=xs, ys=ys, es=es, xnew=np.linspace(-12., 42., m), hyp=hyp,
                     kp=K.kernel_params_1d(hyp),
                     label='128 x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3] / 8)')
+    if name == 'c5':
+        rng = np.random.default_rng(5)                      # same field on every rank, pairs differ
+        n = 16384
+        X = rng.uniform(0., 4096., (n, 2))
+        y = np.sin(X[:, 0] / 300.) * np.cos(X[:, 1] / 340.) + 0.1 * rng.standard_normal(n)
+        sig = np.logspace(-0.5, 0.5, 4)
+        ell = np.logspace(1.5, 2.5, 8)
+        pairs = [(s_, l_) for s_ in sig for l_ in ell]       # 32 (sigma, l) candidates
+        mine = pairs[(rank * 4) % 32:(rank * 4) % 32 + 4]    # 4 per GPU (all 32 on 8 GPUs)
+        return dict(dim=2, n=n, m=0, x=X, y=y, e=np.full(n, 0.1), xnew=None, sweep=mine,
+                    hyp=[mine[0][0], mine[0][1], mine[0][1], 0.],
+                    kp=K.kernel_params_2d([mine[0][0], mine[0][1], mine[0][1], 0.]),
+                    label='2D RBF GP N=16384, log-likelihood sweep, 4 (sigma,l) pairs per GPU per step '
+                          '(BASELINE config[4] / 8)')
     raise SystemExit('unknown workload %r' % name)
 
 
@@ -107,7 +121,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -115,7 +129,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:          # launched by torch.distributed.run (any world size)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -141,6 +155,14 @@ def main():
         ll, info, mu, var = step()
         assert not info.any() and np.all(np.isfinite(mu))
         units_per_step = wl['B']
+    elif 'sweep' in wl:
+        dev.set_data(wl['dim'], wl['x'], wl['y'])
+        diag = K.diag_term(wl['n'], wl['e'], 0., 0.)
+        kps = [K.kernel_params_2d([s_, l_, l_, 0.], sigma2_in_train=True) for s_, l_ in wl['sweep']]
+        lls = [dev.fit(kp, diag)[0] for kp in kps]
+        assert np.all(np.isfinite(lls))
+        mu, var = np.array(lls), np.zeros(len(lls))
+        units_per_step = len(kps)
     else:
         dev.set_data(wl['dim'], wl['x'], wl['y'])
         diag = K.diag_term(wl['n'], wl['e'], 0., 0.)
@@ -159,7 +181,12 @@ def main():
     def run_steps(k):
         # k device-resident fits (or batches of fits) back to back on the handle's stream, then sync:
         # the last cgp_fit / cgp_batch_fit left every input in HBM
-        if k > 0:
+        if 'sweep' in wl:
+            # one hyper-parameter set per evaluation: 6 doubles go down, 1 comes back (data resident)
+            for _ in range(k):
+                for kp in kps:
+                    dev.fit(kp, diag)
+        elif k > 0:
             dev.bench_fit(k, stages=False)
 
     run_steps(args.warmup)
@@ -182,18 +209,25 @@ def main():
     # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
     roof, extra = None, {}
     if not batched:
-        ms_fit, st = dev.bench_fit(min(args.steps, 5), stages=True)
+        ms_fit, st = dev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
         ach = flops / (gemm_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)
+        if os.path.exists(tpath):          # HBM bytes per launch from the separate rocprofv3 --pmc passes
+            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64)', launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5))
         potrf_ms = st[1] + st[2] + st[3]
         chol_flops = n ** 3 / 3.0
         # the sweep also carries the M+1 tall rows (n^2 (m+1) flops): time share by flops
         sweep_flops = chol_flops + float(n) ** 2 * (wl['m'] + 1)
+        if traffic is not None:
+            roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
+                                    'separate rocprofv3 passes, see profiles/')
         extra = dict(ms_per_fit_events=round(ms_fit, 4),
                      stage_ms=dict(assemble_K=round(st[0], 4), potrf_diag=round(st[1], 4), trsm_panel=round(st[2], 4),
                                    gemm_update=round(st[3], 4), assemble_cross=round(st[4], 4), finish=round(st[5], 4)),

@@ -27,8 +27,10 @@ __device__ unsigned long long g_stamps[256];
 #define CGP_STAMP(i) do {} while (0)
 #endif
 
-struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.h
+struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.h ...
     double amp_train, amp_cross, p0, p1, p2, p3;
+    double kss_noise;       // ... plus the K(new,new) diagonal term, kept in HBM so that a captured
+                            // graph can be replayed with new hyper-parameters without re-capturing
 };
 
 // v_mfma_f64_16x16x4_f64.  Lane maps (cdna_hip_programming.md 3, checked by
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
 template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
-    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta) {
+    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -604,7 +606,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
 
     int ti, tj;
     {
-        const int bid = blockIdx.x;
+        // Block ids are dealt round-robin over the 8 XCDs; with the row-major tile order the tiles that
+        // run together on one XCD span ~16 tile rows x 8 columns, i.e. 24 shared panels per 128 tiles.
+        // (A contiguous chunk per XCD was measured WORSE: +15 % HBM fetch, same time.)
+        const int bid = blockIdx.x + tile_skip;   // tile_skip: leading tiles done by another launch
         const int ntri = tri ? nc * (nc + 1) / 2 : 0;
         if (bid < ntri) {
             int i = (int)((sqrtf(8.f * bid + 1.f) - 1.f) * 0.5f);
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finish(
     const double* __restrict__ M, long ld, long sM, int Np, int wrow0, int zrow, int m,
-    const double* __restrict__ mean_new, const KParams* __restrict__ kpp, double kss_noise,
+    const double* __restrict__ mean_new, const KParams* __restrict__ kpp,
     const double* __restrict__ logdet_parts, long sLd, int nblk, const int* __restrict__ ns,
     double* __restrict__ mu, double* __restrict__ var, long sOut, double* __restrict__ scal) {
     const int b = blockIdx.z, t = blockIdx.x;
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(256) void k_finish(
         s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (t < m) {
             mu[(long)b * sOut + t] = s1 + (mean_new ? mean_new[t] : 0.);
-            var[(long)b * sOut + t] = (kpp->amp_train + kss_noise) - s2;
+            var[(long)b * sOut + t] = (kpp->amp_train + kpp->kss_noise) - s2;
         } else {
             const double n = (double)ns[b];
             scal[b * 2 + 0] = -0.5 * s1 - 0.5 * n * 1.8378770664093453 - 0.5 * s2;   // log(2 pi)
@@ -773,16 +778,24 @@ __global__ __launch_bounds__(256) void k_finish(
 // Measurement / self-test kernels
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters) {
-    d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int i = 0; i < iters; ++i) {
-        c0 = mfma16(a, b, c0);
-        c1 = mfma16(a, b, c1);
-        c2 = mfma16(a, b, c2);
-        c3 = mfma16(a, b, c3);
+    // bare v_mfma_f64_4x4x4_4b_f64 issue loop, 16 independent accumulators, varying operands
+    double c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.;
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = 0.37 + 1e-3 * ((threadIdx.x * 7 + i * 13 + blockIdx.x) % 97);
+        b[i] = -0.81 + 1e-3 * ((threadIdx.x * 11 + i * 5 + blockIdx.x) % 89);
     }
-    d4 s = c0 + c1 + c2 + c3;
-    if (s[0] == 12345.678) out[0] = s[1] + s[2] + s[3];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = mfma4(a[i & 3], b[i >> 2], c[i]);
+    }
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += c[i];
+    if (s == 12345.678) out[0] = s;
 }
 
 __global__ __launch_bounds__(256) void k_stream_store(double* out, long n2) {

@@ -102,3 +102,26 @@ class Comm(object):
             block[k, :len(items[u])] = items[u]
         full = self.gather_units(block, n_units)
         return [full[u, :all_lens[u]].copy() for u in range(n_units)]
+
+
+def sweep_log_likelihood(gp, table, comm=None, svd_method=False):
+    """Log-likelihood of `gp` for every hyper-parameter row of `table` (P x nhyp, plus a trailing
+    nugget column when gp.fit_nugget) -- BASELINE config[4]: candidates are independent units, rank r
+    evaluates its contiguous block on its own GPU with the data resident in HBM (only the 6-double
+    kernel-parameter vector and the diagonal go down per candidate, one double comes back) and ONE
+    all_gather returns the P values on every rank.  comm=None: single process."""
+    table = np.asarray(table, dtype=np.float64)
+    n_units = len(table)
+    mine = list(range(n_units)) if comm is None else comm.my_units(n_units)
+    saved_comm = gp.comm
+    gp.comm = None                     # objects are NOT sharded here: candidates are
+    try:
+        vals = []
+        for k in mine:
+            gp.compute_log_likelihood(table[k], svd_method=svd_method)
+            vals.append(gp.log_likelihood[0])
+    finally:
+        gp.comm = saved_comm
+    if comm is None:
+        return np.array(vals)
+    return comm.gather_units(np.array(vals, dtype=np.float64), n_units)

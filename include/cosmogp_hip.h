@@ -141,7 +141,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
  *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit */
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
 
-/* Bare v_mfma_f64_16x16x4_f64 issue loop on every CU: measured fp64 matrix ceiling (TFLOP/s),
+/* Bare v_mfma_f64_4x4x4_4b_f64 issue loop on every CU: measured fp64 matrix ceiling (TFLOP/s),
  * and a streaming-store kernel: measured HBM write ceiling (GB/s). */
 int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs);
 

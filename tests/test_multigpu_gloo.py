@@ -71,6 +71,16 @@ def _worker(rank, world, port, out_dir):
     gp.compute_log_likelihood(g['hyp'], svd_method=False)
     assert gp.log_likelihood.shape == (1,)
     np.testing.assert_allclose(gp.log_likelihood, g['ll3_chol'], rtol=1e-11)
+    # hyper-parameter sweep: candidates sharded over ranks, data resident, one gather
+    table = np.array([[0.5, 6.], [0.6, 7.], [0.7, 8.], [0.8, 9.], [0.9, 10.]])
+    gp1 = cosmogp_amd.gaussian_process(ys[0], xs[0], kernel='RBF1D', y_err=es[0], device=FakeDevice())
+    got = multigpu.sweep_log_likelihood(gp1, table, comm)
+    import importlib
+    orc = importlib.import_module('oracle.cosmogp_oracle')
+    ref = [orc.total_log_likelihood([ys[0]], [xs[0]], 'RBF1D', h, 0., [es[0]], [0.], svd_method=False)[0]
+           for h in table]
+    np.testing.assert_allclose(got, ref, rtol=1e-11)
+    assert gp1.device.calls.count('set_data') == 1 and gp1.device.calls.count('fit') == len(comm.my_units(5))
     comm.barrier()
     open(os.path.join(out_dir, 'ok_%d' % rank), 'w').write('ok')
     dist.destroy_process_group()
