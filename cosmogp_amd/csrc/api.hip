@@ -183,7 +183,7 @@ int leaf_attr_once(cgp_handle* h) {
 // the region are lower-triangular (tile granularity), the rest full.
 int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
                 long ld, long sAB, long rows, long cols, long K, bool tri, double alpha, double beta,
-                hipStream_t stream = nullptr, int tile_skip = 0) {
+                hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
     StageScope sc(h, ST_GEMM);
@@ -194,9 +194,13 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
         if (tile_skip == 0) h->gemm_flops += 2.0 * K * elems * B;
     }
-    if (tiles * B >= GEMM_BIG_TILE_THRESHOLD) {
-        dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<128, 128, 4, 4, GEMM_KB_BIG>), g, dim3(1024), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+    if (bulk_cap > 0 && B == 1 && tile_skip == 0) {
+        // bulk form: 128 x 128 tiles, 8 waves, one workgroup per CU (162 VGPRs x 2 waves/SIMD), persistent
+        // over the tile list with at most bulk_cap workgroups so that 256 - bulk_cap CUs stay free.
+        // Kept for the stream-overlap experiments of DESIGN.md 4.3 (measured 10-15 % slower than the
+        // 64 x 64 form at N = 8192, so no caller passes bulk_cap today).
+        dim3 g((unsigned)std::min<long>(tiles, bulk_cap), 1, 1);
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, 0);
     } else {
         nr = rows / 64; nc = cols / 64;

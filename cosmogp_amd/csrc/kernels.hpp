@@ -604,13 +604,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     A += (long)bz * sAB;
     B += (long)bz * sAB;
 
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
+    const int srow = tid / CPR, sch = (tid % CPR) * 2;   // staging: RSTEP rows x CPR chunks of 16 B
+    const int ntri = tri ? nc * (nc + 1) / 2 : 0;
+    const int ntot = ntri + (nr - (tri ? nc : 0)) * nc;
+    // Persistent tile loop: a launch with fewer workgroups than tiles walks the tile list with stride
+    // gridDim.x (bulk updates are launched with <= 240 workgroups of this 1-per-CU kernel so that some
+    // CUs stay free for the latency-critical leaf kernels of the other stream).
+    for (int bid = blockIdx.x + tile_skip; bid < ntot; bid += gridDim.x) {
     int ti, tj;
     {
         // Block ids are dealt round-robin over the 8 XCDs; with the row-major tile order the tiles that
         // run together on one XCD span ~16 tile rows x 8 columns, i.e. 24 shared panels per 128 tiles.
         // (A contiguous chunk per XCD was measured WORSE: +15 % HBM fetch, same time.)
-        const int bid = blockIdx.x + tile_skip;   // tile_skip: leading tiles done by another launch
-        const int ntri = tri ? nc * (nc + 1) / 2 : 0;
         if (bid < ntri) {
             int i = (int)((sqrtf(8.f * bid + 1.f) - 1.f) * 0.5f);
             while ((i + 1) * (i + 2) / 2 <= bid) ++i;
@@ -623,12 +631,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
             tj = r % nc;
         }
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
     const double* Ag = A + (long)(ti * TM) * ld;
     const double* Bg = B + (long)(tj * TN) * ld;
-    const int srow = tid / CPR, sch = (tid % CPR) * 2;   // staging: RSTEP rows x CPR chunks of 16 B
 
     double acc[MT][NJ];
 #pragma unroll
@@ -720,6 +724,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
 #pragma unroll
             for (int j = 0; j < NJ; ++j) Cg[(long)(i * 16) * ldc + j * 4] = alpha * acc[i][j];
     }
+    }   // persistent tile loop
 }
 
 // ------------------------------------------------------------------------------------

@@ -475,3 +475,54 @@ def test_c4_batch_1024_lightcurves(cg):
         assert abs(l0 - ll[b]) <= 1e-9 * abs(l0)
         np.testing.assert_allclose(mu[b], m0, rtol=0, atol=1e-8)
         np.testing.assert_allclose(var[b], v0, rtol=0, atol=1e-8)
+
+
+def test_eager_graph_lookahead_bit_identical(cg, monkeypatch):
+    """The device-side fit is captured into a hipGraph with a two-stream look-ahead; eager single-stream
+    launches (CGP_NO_GRAPH) and the graph without look-ahead (CGP_NO_OVERLAP) must give bit-identical
+    results (same kernels, same floating-point order).  Each mode uses a fresh handle (graphs are cached)."""
+    from cosmogp_amd import kernel as K
+    from cosmogp_amd import _lib
+    rng = np.random.default_rng(77)
+    n, m = 1500, 333
+    x = np.sort(rng.uniform(0, 600., n))
+    xn = rng.uniform(0, 600., m)
+    y = np.sin(0.05 * x) + 0.1 * rng.standard_normal(n)
+    kp, dg = K.kernel_params_1d([1., 2.]), K.diag_term(n, np.full(n, 0.1), 0., 0.)
+    outs = []
+    for env in ({}, {'CGP_NO_OVERLAP': '1'}, {'CGP_NO_GRAPH': '1'}):
+        for k in ('CGP_NO_OVERLAP', 'CGP_NO_GRAPH'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = _lib.Device(0)
+        dev.set_data(1, x, y)
+        first = dev.fit(kp, dg, xn, None, 0.)
+        again = dev.fit(kp, dg, xn, None, 0.)           # replay of the cached graph
+        assert first[0] == again[0] and np.array_equal(first[2], again[2]) and np.array_equal(first[3], again[3])
+        outs.append(first)
+        dev.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1]
+        assert np.array_equal(o[2], outs[0][2]) and np.array_equal(o[3], outs[0][3])
+
+
+def test_graph_replay_with_new_hyperparameters(cg):
+    """A cached graph only points at HBM buffers: new kernel parameters / diagonal / residual through the
+    same handle must give the new answer (find_hyperparameters relies on this)."""
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(78)
+    n = 700
+    x = np.sort(rng.uniform(0, 100., n))
+    e = rng.uniform(0.05, 0.1, n)
+    y = np.sin(0.3 * x) + e * rng.standard_normal(n)
+    dev = cg.default_device()
+    dev.set_data(1, x, y)
+    for hyp, ng in (([1., 2.], 0.), ([0.7, 3.5], 0.05), ([1.3, 1.1], 0.0)):
+        ll = dev.fit(K.kernel_params_1d(hyp), K.diag_term(n, e, 0., ng))[0]
+        ref = orc.log_likelihood_gp(y, x, 'RBF1D', hyp, ng, y_err=e, svd_method=False)[0]
+        assert abs(ll - ref) <= 1e-11 * abs(ref)
+    dev.set_data(1, x, 2. * y)                               # new residual, same shape -> same graph
+    ll2 = dev.fit(K.kernel_params_1d([1., 2.]), K.diag_term(n, e, 0., 0.))[0]
+    ref2 = orc.log_likelihood_gp(2. * y, x, 'RBF1D', [1., 2.], 0., y_err=e, svd_method=False)[0]
+    assert abs(ll2 - ref2) <= 1e-11 * abs(ref2)
