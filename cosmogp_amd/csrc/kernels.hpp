@@ -242,14 +242,15 @@ __global__ void k_pad_square(const double* __restrict__ src, long lds, double* _
 // Pivot arithmetic of the elimination.  Measured dependent latencies of fp64 VALU ops on gfx950
 // (tools/lat_f64.hip): v_fma_f64 32, v_mul/v_add_f64 44, v_rsq_f64 ~52, v_readlane pair + use ~56
 // cycles, so the pivot chain is written for minimum DEPTH: y = rsq(d) is refined in one shot,
-//   1/sqrt(d) = y (1 + e/2 + 3 e^2/8 + 5 e^3/16),  e = 1 - d y^2   (error O(e^4)),
-// applied directly to the column value:  l = v y + (v y e) p.
+//   1/sqrt(d) = y (1 + e/2 + 3 e^2/8),  e = 1 - d y^2,
+// applied directly to the column value:  l = v y + (v y e) p.  V_RSQ_F64 is accurate to 2^29 ulp
+// (|e| <= 2^-22), so the truncation error 5 e^3 / 16 is < 1e-20: no further term is needed.
 __device__ __forceinline__ void pivot_scale(double d, double v, double& l, double& sd) {
     const double y = __builtin_amdgcn_rsq(d);
     const double t = d * y;                 // ~ sqrt(d)
     const double vy = v * y;
     const double e = __builtin_fma(-t, y, 1.0);
-    const double p = __builtin_fma(__builtin_fma(0.3125, e, 0.375), e, 0.5);
+    const double p = __builtin_fma(0.375, e, 0.5);
     l = __builtin_fma(vy * e, p, vy);
     sd = __builtin_fma(t * e, p, t);        // off the chain: only stored
 }
@@ -311,21 +312,30 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     CGP_STAMP(1);
 
     int bad = 0;   // 1-based local index of the first non-positive pivot (wave 0 only)
-    int pending_s = -1;
+    // Schedule of sub-step s (two workgroup barriers; everything that is not on the pivot chain runs
+    // under phase (a) of the pivot wave):
+    //   I1  wave 0 : (a)(s)  factor T = tile (s,s), produce T^-T
+    //       others : trailing tiles of sub-step s-1, C[ti][tj] -= P_i P_j^T for ti >= tj >= s, (ti,tj) != (s,s)
+    //   -- barrier --
+    //   I2  wave 0 : (c0) P[s+1] = A[s+1][s] T^-T, then (e0) tile (s+1,s+1) -= P[s+1] P[s+1]^T
+    //       others : (c) P[ti] = A[ti][s] T^-T for ti >= s+2
+    //   -- barrier --
     for (int s = 0; s < 8; ++s) {
         const int o = s * 16;
         CGP_STAMP(2 + 4 * s);
-        if (wave != 0 && pending_s >= 0) {
-            // (e2) of sub-step pending_s: tiles (ti >= tj >= pending_s + 2), waves 1..
-            const int ps = pending_s, po = ps * 16;
-            const int w = 6 - ps;                       // tile rows/cols left after column ps+1
+        // workers of I1 = waves that do NOT share SIMD 0 with the pivot wave (waves go to SIMDs round
+        // robin, so wave 4 sits beside wave 0 and stays idle here: the pivot chain is issue-sensitive)
+        const int worker = (wave & 3) ? (wave - 1 - (wave >> 2)) : -1;      // 1,2,3,5,6,7 -> 0..5
+        if (worker >= 0 && s > 0) {
+            const int po = (s - 1) * 16;
+            const int w = 8 - s;                        // tile rows/cols s..7
             const int ntile = w * (w + 1) / 2;
-            for (int t = wave - 1; t < ntile; t += CGP_K3_WAVES - 1) {
+            for (int t = 1 + worker; t < ntile; t += 6) {   // t = 0 is tile (s,s): done by wave 0
                 int i = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
                 while ((i + 1) * (i + 2) / 2 <= t) ++i;
                 while (i * (i + 1) / 2 > t) --i;
                 const int j = t - i * (i + 1) / 2;
-                const int ti = ps + 2 + i, tj = ps + 2 + j;
+                const int ti = s + i, tj = s + j;
                 double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
                 double acc[4];
 #pragma unroll
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
         }
         if (wave == 0) {
             // lanes 0..15: rows of T; lanes 16..31: rows of the identity (-> T^-T); others idle.
-            // Column j: pivot by readlane, 1/sqrt by rsq + Goldschmidt, column j+1 is updated at
+            // Column j: pivot by readlane, 1/sqrt by rsq + one-shot refinement, column j+1 is updated at
             // once through readlane (it is on the critical chain), columns >= j+2 one step later
             // from an LDS broadcast of the scaled column (fills the latency of the next chain).
             double v[16], lprev = 0., pv;
@@ -390,8 +400,10 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
         }
         __syncthreads();
         CGP_STAMP(3 + 4 * s);
-        // (c) sub-panel rows below T:  P[ti] = A[ti][s] * T^-T   (B[k][n] = Ws[s][k][n])
-        for (int ti = s + 1 + wave; ti < 8; ti += CGP_K3_WAVES) {
+        // I2: sub-panel  P[ti] = A[ti][s] * T^-T  (B[k][n] = Ws[s][k][n]); wave 0 takes ti = s+1 and then
+        // the diagonal tile (s+1,s+1), the other waves share ti >= s+2
+        for (int ti = (wave == 0 ? s + 1 : s + 1 + wave); ti < (wave == 0 ? min(s + 2, 8) : 8);
+             ti += CGP_K3_WAVES - 1) {
             double acc[4] = {0., 0., 0., 0.};
             const double* Arow = As + (ti * 16) * CGP_LDA + o;
 #pragma unroll
@@ -409,27 +421,24 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
                 for (int J = 0; J < 4; ++J) acc[J] = mfma4(a.y, b1[J], acc[J]);
             }
             // acc[J] at lane (u, blk, q) = P[16 ti + 4 blk + q][4 J + u]
+            wave_lds_fence();
 #pragma unroll
             for (int J = 0; J < 4; ++J) As[(ti * 16 + 4 * lb + lq) * CGP_LDA + o + 4 * J + lu] = acc[J];
         }
-        __syncthreads();
-        CGP_STAMP(4 + 4 * s);
-        // (e) trailing tiles (ti >= tj > s):  C[ti][tj] -= P[ti] P[tj]^T, in two parts so that the
-        // next pivot block overlaps the bulk of it (look-ahead inside the leaf):
-        //   (e1) tile column s+1 (what phase (a) of s+1 and its sub-panel need), all waves;
-        //   (e2) tile columns >= s+2, by waves 1.. while wave 0 already runs phase (a) of s+1.
-        for (int ti = s + 1 + wave; ti < 8; ti += CGP_K3_WAVES) {
-            const int tj = s + 1;
-            double* Ct = As + (ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu;
+        if (wave == 0 && s < 7) {
+            // (e0): tile (s+1,s+1) -= P[s+1] P[s+1]^T, P[s+1] just written by this wave
+            wave_lds_fence();
+            const int t1 = s + 1;
+            double* Ct = As + (t1 * 16 + 4 * lb + lq) * CGP_LDA + t1 * 16 + lu;
             double acc[4];
 #pragma unroll
             for (int J = 0; J < 4; ++J) acc[J] = Ct[4 * J];
-            tile_mma_nt<true>(acc, As + (ti * 16) * CGP_LDA + o, As + (tj * 16) * CGP_LDA + o, lr, lu, lq);
+            tile_mma_nt<true>(acc, As + (t1 * 16) * CGP_LDA + o, As + (t1 * 16) * CGP_LDA + o, lr, lu, lq);
 #pragma unroll
             for (int J = 0; J < 4; ++J) Ct[4 * J] = acc[J];
         }
         __syncthreads();
-        pending_s = s;        // (e2) of this sub-step is done at the top of the next iteration
+        CGP_STAMP(4 + 4 * s);
     }
 
     CGP_STAMP(40);
