@@ -44,7 +44,6 @@ struct Prob {
     double* r = nullptr;      long sr = 0;
     double* diag = nullptr;   long sd = 0;
     double* xnew = nullptr;   long sxn = 0;   // 0 = shared grid
-    double* z = nullptr;                       // solved residual rows, stride Np
     double* wsW = nullptr;    long sW = 0;
     double* ldp = nullptr;    long sLd = 0;
     int* info = nullptr;
@@ -73,12 +72,12 @@ struct cgp_handle {
     bool last_has_mean = false;
     double last_kss_noise = 0.;
     bool last_was_batch = false;
-    DevBuf bM, bx, br, bdiag, bxnew, bz, bws, bldp, binfo, bns, bmean, bmu, bvar, bscal, bkp;
+    DevBuf bM, bx, br, bdiag, bxnew, bws, bldp, binfo, bns, bmean, bmu, bvar, bscal, bkp;
     DevBuf bC, bout, bns2, bdiag2;            // scratch: square outputs
-    DevBuf box, boxn, bzero;                  // operator-level scratch
+    DevBuf box, boxn;                         // operator-level scratch
     // batched state
     Prob Q;
-    DevBuf qM, qx, qr, qdiag, qxnew, qz, qws, qldp, qinfo, qns, qmean, qmu, qvar, qscal;
+    DevBuf qM, qx, qr, qdiag, qxnew, qws, qldp, qinfo, qns, qmean, qmu, qvar, qscal;
     // captured device-side fit (hipGraph), replayed while shapes and buffers stay the same
     struct GraphKey {
         const void* ptrs[16];
@@ -365,9 +364,9 @@ int cgp_destroy(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf* all[] = {&h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bz, &h->bws, &h->bldp, &h->binfo, &h->bns,
+    DevBuf* all[] = {&h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
-                     &h->box, &h->boxn, &h->bzero, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qz, &h->qws,
+                     &h->box, &h->boxn, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
                      &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
     for (DevBuf* b : all) free_buf(*b);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -430,14 +429,12 @@ int bind_single(cgp_handle* h, long tall, bool keep_factor) {
     else CHK(ensure(h, h->bM, need));
     P.M = (double*)h->bM.p;
     const long nblk = P.Np / NB;
-    CHK(ensure(h, h->bz, P.Np * sizeof(double)));
     if (!keep_factor) {
         CHK(ensure(h, h->bws, nblk * 8 * 256 * sizeof(double)));
         CHK(ensure(h, h->bldp, nblk * sizeof(double)));
         CHK(ensure(h, h->binfo, sizeof(int)));
         CHK(ensure(h, h->bscal, 2 * sizeof(double)));
     }
-    P.z = (double*)h->bz.p;
     P.wsW = (double*)h->bws.p; P.sW = nblk * 8 * 256;
     P.ldp = (double*)h->bldp.p; P.sLd = nblk;
     P.info = (int*)h->binfo.p;
@@ -472,8 +469,6 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         CHK(put_resid_row(h, P));
     }
     CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
-    HIPCHK(hipMemcpy2DAsync(P.z, P.Np * sizeof(double), P.M + (P.R - 1) * ld, P.sM * sizeof(double),
-                            P.Np * sizeof(double), P.B, hipMemcpyDeviceToDevice, h->stream));
     CHK(launch_finish(h, P, m, true, has_mean));
     return 0;
 }
@@ -486,7 +481,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     if (!h->use_graph || h->profiling || getenv("CGP_NO_GRAPH")) return device_fit_eager(h, P, m, has_mean);
     cgp_handle::GraphKey key;
     std::memset(&key, 0, sizeof(key));
-    const void* ptrs[16] = {P.M, P.x, P.r, P.diag, P.xnew, P.z, P.wsW, P.ldp, P.info, P.ns, P.mean, P.mu, P.var,
+    const void* ptrs[16] = {P.M, P.x, P.r, P.diag, P.xnew, nullptr, P.wsW, P.ldp, P.info, P.ns, P.mean, P.mu, P.var,
                             P.scal, h->bkp.p, nullptr};
     std::memcpy(key.ptrs, ptrs, sizeof(ptrs));
     key.B = P.B; key.Np = P.Np; key.R = P.R; key.m = m; key.dim = P.dim; key.has_mean = has_mean ? 1 : 0;
@@ -789,7 +784,6 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     CHK(ensure(h, h->qr, hr.size() * sizeof(double)));
     CHK(ensure(h, h->qdiag, hd.size() * sizeof(double)));
     CHK(ensure(h, h->qns, B * sizeof(int)));
-    CHK(ensure(h, h->qz, (size_t)B * Np * sizeof(double)));
     CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
     CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
     CHK(ensure(h, h->qinfo, B * sizeof(int)));
@@ -817,7 +811,6 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     Q.r = (double*)h->qr.p; Q.sr = Np;
     Q.diag = (double*)h->qdiag.p; Q.sd = Np;
     Q.xnew = (double*)h->qxnew.p; Q.sxn = (xnew_per_object && m > 0) ? Mp * dim : 0;
-    Q.z = (double*)h->qz.p;
     Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
     Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
     Q.info = (int*)h->qinfo.p;

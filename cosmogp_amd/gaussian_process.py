@@ -34,6 +34,13 @@ from .mean import return_mean
 
 REFERENCE_STALE_INDEX = False
 
+#: Opt-in (SURVEY.md 7 "hard parts"): when True, calls made with the reference's default
+#: svd_method=True first try the GPU Cholesky path, which equals the SVD pseudo-inverse to ~1e-13
+#: whenever K is positive definite (no singular value <= 1e-15 is dropped), and only fall back to the
+#: host SVD when the factorisation reports a non-positive pivot.  False (default) keeps the reference
+#: semantics exactly: svd_method=True always means the SVD algorithm.
+SVD_VIA_CHOLESKY_WHEN_PD = False
+
 #: objects per batched launch sequence are capped so that B * (Np + 128) * Np * 8 bytes
 #: stays below this (HBM is 288 GB; leave room for several handles)
 BATCH_BYTES_LIMIT = 64 << 30
@@ -213,6 +220,11 @@ class Gaussian_process(object):
             Nugget = self.nugget
             hyperparameter = Hyperparameter
         objs = self._my_objects()
+        if svd_method and SVD_VIA_CHOLESKY_WHEN_PD:
+            try:
+                return self.compute_log_likelihood(Hyperparameter, svd_method=False)
+            except np.linalg.LinAlgError:
+                pass
         if svd_method:
             per_obj = [log_likelihood_gp(self.y[sn], self.Time[sn], self.kernel, hyperparameter, Nugget,
                                          y_err=self.y_err[sn], y_mean=self.y0[sn], svd_method=True,
@@ -310,6 +322,12 @@ class Gaussian_process(object):
         nugget = self.nugget
         self.Prediction = [None] * self.N_sn
         self.variance = [None] * self.N_sn
+        if svd_method and SVD_VIA_CHOLESKY_WHEN_PD:
+            try:
+                return self.get_prediction(new_binning=new_binning, COV=COV, svd_method=False)
+            except np.linalg.LinAlgError:
+                self.Prediction = [None] * self.N_sn
+                self.variance = [None] * self.N_sn
         if svd_method:
             self._predict_svd(hyp, nugget, COV)
             return

@@ -526,3 +526,27 @@ def test_graph_replay_with_new_hyperparameters(cg):
     ll2 = dev.fit(K.kernel_params_1d([1., 2.]), K.diag_term(n, e, 0., 0.))[0]
     ref2 = orc.log_likelihood_gp(2. * y, x, 'RBF1D', [1., 2.], 0., y_err=e, svd_method=False)[0]
     assert abs(ll2 - ref2) <= 1e-11 * abs(ref2)
+
+
+def test_svd_method_optin_routes_to_cholesky_when_pd(cg):
+    """Opt-in: svd_method=True (the reference default) tries the GPU Cholesky first; on PD input it agrees
+    with the golden SVD answers, on singular input it falls back to the host SVD like the reference."""
+    import sys
+    gpm = sys.modules['cosmogp_amd.gaussian_process']
+    g = load_golden('c1_predict_1d_n256')
+    gp = cg.gaussian_process(g['y'], g['x'], y_err=g['e'])
+    gp.hyperparameters = g['hyp']
+    try:
+        gpm.SVD_VIA_CHOLESKY_WHEN_PD = True
+        gp.get_prediction(new_binning=g['xnew'], svd_method=True)
+        np.testing.assert_allclose(gp.Prediction[0], g['pred_svd'], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(gp.variance[0], g['cov_diag_svd'], rtol=0, atol=1e-8)
+        gp.compute_log_likelihood(g['hyp'], svd_method=True)
+        np.testing.assert_allclose(gp.log_likelihood, g['loglik'], rtol=1e-10)
+        x = np.linspace(0, 5, 60)
+        gs = cg.gaussian_process(np.sin(x), x)                      # noise-free: singular K
+        gs.hyperparameters = np.array([1., 2.])
+        gs.get_prediction(new_binning=x[:5], svd_method=True)        # falls back, never raises
+        assert np.all(np.isfinite(gs.Prediction[0]))
+    finally:
+        gpm.SVD_VIA_CHOLESKY_WHEN_PD = False
