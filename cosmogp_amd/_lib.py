@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_fit_set_data', 'cgp_fit',
-    'cgp_fit_predict', 'cgp_fit_fetch', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 
@@ -63,6 +63,7 @@ def load_library():
         lib.cgp_fit.argtypes = [vp, _dp, _dp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp, _dp]
         lib.cgp_fit_predict.argtypes = [vp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp]
         lib.cgp_fit_fetch.argtypes = [vp, ctypes.c_int, _dp]
+        lib.cgp_batch_set_data.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp]
         lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
                                       _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
@@ -113,6 +114,8 @@ class Device(object):
         #: bumped whenever the resident single-object factor is replaced (lazy attributes
         #: of Gaussian_process check it before fetching from the device)
         self.generation = 0
+        self.batch_generation = 0       # same for the resident batch
+        self._batch = None
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -138,7 +141,7 @@ class Device(object):
     def rbf(self, dim, x, kp, xnew=None, diag=None):
         x = _f64(x)
         n = x.shape[0]
-        kp = _f64(kp, (6,))
+        kp = _f64(kp, (7,))
         if xnew is None:
             out = np.empty((n, n))
             dg = None if diag is None else _f64(diag, (n,))
@@ -173,8 +176,10 @@ class Device(object):
         self.dim, self.n = dim, n
 
     def fit(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., want_var=True):
-        """Returns (loglik, logdet, mu, var); mu/var None when xnew is None."""
-        kp = _f64(kp, (6,))
+        """Returns (loglik, logdet, mu, var); mu/var None when xnew is None.
+        diag: uploaded and kept resident; None keeps the resident vector (zeros after set_data);
+        kp[6] is added to every element of it on the device."""
+        kp = _f64(kp, (7,))
         dg = None if diag is None else _f64(diag, (self.n,))
         ll, ld = ctypes.c_double(0.), ctypes.c_double(0.)
         if xnew is None:
@@ -209,17 +214,24 @@ class Device(object):
         return out
 
     # ---- batched -------------------------------------------------------------------
-    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.,
-                  xnew_per_object=False):
-        """xs / resids / diags: lists of per-object arrays (ragged allowed).  xnew: (m,[2]) grid
-        shared by all objects, or (B, m,[2]) with xnew_per_object=True.
-        Returns (loglik[B], info[B], mu[B,m] or None, var[B,m] or None)."""
+    def batch_set_data(self, dim, xs, resids, diags=None):
+        """Upload B objects (lists of per-object arrays, ragged allowed) and keep them resident."""
         B = len(xs)
         ns = np.array([len(r) for r in resids], dtype=np.int64)
         x = _f64(np.concatenate([np.asarray(a, dtype=np.float64).reshape(len(a), -1) for a in xs]).ravel())
         r = _f64(np.concatenate(resids))
         d = None if diags is None else _f64(np.concatenate(diags))
-        kp = _f64(kp, (6,))
+        self.batch_generation += 1
+        st = self._lib.cgp_batch_set_data(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
+                                          _ptr(d))
+        self._check(st, 'cgp_batch_set_data')
+        self._batch = (dim, B)
+
+    def batch_fit_resident(self, kp, xnew=None, mean_new=None, kss_noise=0., xnew_per_object=False):
+        """Fit the resident batch: only kp (7 doubles) and the prediction grid go down.
+        Returns (loglik[B], info[B], mu[B,m] or None, var[B,m] or None)."""
+        dim, B = self._batch
+        kp = _f64(kp, (7,))
         ll = np.empty(B)
         info = np.zeros(B, dtype=np.int32)
         if xnew is None:
@@ -231,12 +243,18 @@ class Device(object):
                 raise ValueError('per-object grids need shape (B, m[, 2])')
             mu, var = np.empty((B, m)), np.empty((B, m))
             mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
-        st = self._lib.cgp_batch_fit(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
-                                     _ptr(d), _ptr(kp), _ptr(xn), m, 1 if xnew_per_object else 0, _ptr(mn),
-                                     float(kss_noise), _ptr(ll),
+        st = self._lib.cgp_batch_fit(self._h, dim, B, None, None, None, None, _ptr(kp), _ptr(xn), m,
+                                     1 if xnew_per_object else 0, _ptr(mn), float(kss_noise), _ptr(ll),
                                      info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(mu), _ptr(var))
         self._check(st, 'cgp_batch_fit')
         return ll, info, mu, var
+
+    def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.,
+                  xnew_per_object=False):
+        """Upload + fit in one go (see batch_set_data / batch_fit_resident).  xnew: (m,[2]) grid shared by
+        all objects, or (B, m,[2]) with xnew_per_object=True."""
+        self.batch_set_data(dim, xs, resids, diags)
+        return self.batch_fit_resident(kp, xnew, mean_new, kss_noise, xnew_per_object)
 
     # ---- measurement ---------------------------------------------------------------
     def bench_fit(self, iters, stages=True):

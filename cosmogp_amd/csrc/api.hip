@@ -67,7 +67,7 @@ struct cgp_handle {
     std::string err;
     // single-object state
     Prob P;
-    bool have_data = false, factored = false;
+    bool have_data = false, factored = false, have_batch = false;
     long last_m = 0;
     bool last_has_mean = false;
     double last_kss_noise = 0.;
@@ -170,7 +170,8 @@ struct StageScope {
 };
 
 int leaf_attr_once(cgp_handle* h) {
-    static bool done = false;
+    static bool done_dev[64] = {false};          // the attribute is per device
+    bool& done = done_dev[h->device & 63];
     if (done) return 0;
     HIPCHK(hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
     HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
@@ -277,18 +278,20 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
 
 template <int DIM>
 int launch_assemble_train_t(cgp_handle* h, int B, double* M, long ld, long sM, const double* x, long sx,
-                            const double* diag, long sd, const int* ns, long Np, bool lower_only) {
+                            const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2) {
     dim3 g((unsigned)(Np / 128), (unsigned)(Np / 64), (unsigned)B);
     hipLaunchKernelGGL((k_assemble_train<DIM>), g, dim3(256), 0, h->stream, M, ld, sM, x, sx, diag, sd, ns,
-                       (const KParams*)h->bkp.p, lower_only ? 1 : 0);
+                       (const KParams*)h->bkp.p, lower_only ? 1 : 0, use_nug2 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
+// use_nug2: add kp.nug2 to the diagonal vector (the training matrix of a fit); false for K(new,new),
+// whose diagonal term is passed explicitly
 int launch_assemble_train(cgp_handle* h, int dim, int B, double* M, long ld, long sM, const double* x, long sx,
-                          const double* diag, long sd, const int* ns, long Np, bool lower_only) {
-    return dim == 1 ? launch_assemble_train_t<1>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only)
-                    : launch_assemble_train_t<2>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only);
+                          const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2) {
+    return dim == 1 ? launch_assemble_train_t<1>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2)
+                    : launch_assemble_train_t<2>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2);
 }
 
 int launch_assemble_cross(cgp_handle* h, int dim, int B, double* Mrows, long ld, long sM, const double* x, long sx,
@@ -405,6 +408,7 @@ int begin_call(cgp_handle* h) {
 int upload_kp(cgp_handle* h, const double* kp, double kss_noise) {
     KParams k;
     k.amp_train = kp[0]; k.amp_cross = kp[1]; k.p0 = kp[2]; k.p1 = kp[3]; k.p2 = kp[4]; k.p3 = kp[5];
+    k.nug2 = kp[6];
     k.kss_noise = kss_noise;
     HIPCHK(hipMemcpyAsync(h->bkp.p, &k, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -459,7 +463,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int) * P.B, h->stream));
     {
         StageScope sc(h, ST_ASM_K);
-        CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true));
+        CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true));
     }
     {
         StageScope sc(h, ST_ASM_H);
@@ -536,6 +540,7 @@ int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resi
     P.Np = round_up(n, NB);
     CHK(upload_padded(h, h->bx, x, (size_t)n * dim, (size_t)P.Np * dim));
     CHK(upload_padded(h, h->br, resid, (size_t)n, (size_t)P.Np));
+    CHK(upload_padded(h, h->bdiag, nullptr, 0, (size_t)P.Np));       // resident diagonal := zeros
     CHK(ensure(h, h->bns, sizeof(int)));
     int ni = (int)n;
     HIPCHK(hipMemcpyAsync(h->bns.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -554,7 +559,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     const long Mp = round_up(m + 1, NB);
     CHK(bind_single(h, Mp, false));
     CHK(upload_kp(h, kp, kss_noise));
-    CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
+    if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));   // NULL: keep the resident one
     CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
     CHK(upload_padded(h, h->bmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
     CHK(ensure(h, h->bmu, Mp * sizeof(double)));
@@ -618,7 +623,7 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
         HIPCHK(hipMemcpyAsync(h->bns2.p, &mi, sizeof(int), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mp, kss_noise);
         CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, Mp, 0, P.xnew, 0, (double*)h->bdiag2.p, 0,
-                                  (int*)h->bns2.p, Mp, false));
+                                  (int*)h->bns2.p, Mp, false, false));
         CHK(launch_gemm(h, 1, (double*)h->bC.p, Mp, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, Mp, Mp, P.Np, false,
                         -1.0, 1.0));
         hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->bC.p, Mp,
@@ -668,7 +673,7 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out) {
     if (which == CGP_MAT_K) {
         if (!h->have_data || !h->bdiag.p) return fail(h, CGP_E_STATE, "cgp_fit_fetch(K): no fit yet");
         CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
-        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, P.Np, 0, P.x, 0, P.diag, 0, P.ns, P.Np, false));
+        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, P.Np, 0, P.x, 0, P.diag, 0, P.ns, P.Np, false, true));
         return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 0, out);
     }
     if (!h->factored) return fail(h, CGP_E_STATE, "cgp_fit_fetch: no factor");
@@ -732,7 +737,7 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xn
         CHK(upload_padded(h, h->bdiag2, diag, diag ? (size_t)n : 0, (size_t)Np));
         CHK(ensure(h, h->bC, (size_t)Np * Np * sizeof(double)));
         CHK(launch_assemble_train(h, dim, 1, (double*)h->bC.p, Np, 0, (double*)h->box.p, 0, (double*)h->bdiag2.p, 0,
-                                  (int*)h->bns2.p, Np, false));
+                                  (int*)h->bns2.p, Np, false, true));
         HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), n,
                                 hipMemcpyDeviceToHost, h->stream));
     } else {
@@ -748,25 +753,20 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xn
     return CGP_OK;
 }
 
-int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
-                  const double* diag, const double* kp, const double* xnew, int64_t m, int xnew_per_object,
-                  const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu,
-                  double* var) {
+int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
+                       const double* diag) {
     CHK(begin_call(h));
-    if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid || !kp || m < 0 || (m > 0 && (!xnew || !mu)))
-        return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
+    if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid)
+        return fail(h, CGP_E_ARG, "cgp_batch_set_data: bad argument");
     long nmax = 0;
     for (long b = 0; b < B; ++b) {
-        if (ns[b] <= 0) return fail(h, CGP_E_ARG, "cgp_batch_fit: ns[b] <= 0");
+        if (ns[b] <= 0) return fail(h, CGP_E_ARG, "cgp_batch_set_data: ns[b] <= 0");
         nmax = std::max<long>(nmax, ns[b]);
     }
     Prob& Q = h->Q;
     Q.B = (int)B; Q.dim = dim; Q.n = nmax;
     Q.Np = round_up(nmax, NB);
-    const long Mp = round_up(m + 1, NB);
-    Q.R = Q.Np + Mp;
-    Q.sM = Q.R * Q.Np;
-    const long Np = Q.Np, nblk = Np / NB;
+    const long Np = Q.Np;
     // pack ragged host arrays into padded [B][Np] layouts
     std::vector<double> hx((size_t)B * Np * dim, 0.), hr((size_t)B * Np, 0.), hd((size_t)B * Np, 0.);
     std::vector<int> hn(B);
@@ -779,21 +779,43 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
         if (diag) std::memcpy(&hd[(size_t)b * Np], diag + off, nb * sizeof(double));
         off += nb;
     }
-    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
     CHK(ensure(h, h->qx, hx.size() * sizeof(double)));
     CHK(ensure(h, h->qr, hr.size() * sizeof(double)));
     CHK(ensure(h, h->qdiag, hd.size() * sizeof(double)));
     CHK(ensure(h, h->qns, B * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(h->qx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qr.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qdiag.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));       // host staging vectors die here
+    h->have_batch = true;
+    return CGP_OK;
+}
+
+int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
+                  const double* diag, const double* kp, const double* xnew, int64_t m, int xnew_per_object,
+                  const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu,
+                  double* var) {
+    if (x || resid) {          // data given: upload it first; x == resid == NULL: use the resident batch
+        int st = cgp_batch_set_data(h, dim, B, ns, x, resid, diag);
+        if (st != 0) return st;
+    }
+    CHK(begin_call(h));
+    Prob& Q = h->Q;
+    if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit: no resident batch (call cgp_batch_set_data)");
+    if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
+        return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
+    const long Mp = round_up(m + 1, NB);
+    Q.R = Q.Np + Mp;
+    Q.sM = Q.R * Q.Np;
+    const long Np = Q.Np, nblk = Np / NB;
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
     CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
     CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
     CHK(ensure(h, h->qinfo, B * sizeof(int)));
     CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
     CHK(ensure(h, h->qmu, (size_t)B * Mp * sizeof(double)));
     CHK(ensure(h, h->qvar, (size_t)B * Mp * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->qx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qr.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qdiag.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     CHK(upload_kp(h, kp, kss_noise));
     if (xnew_per_object && m > 0) {
         std::vector<double> hxn((size_t)B * Mp * dim, 0.);

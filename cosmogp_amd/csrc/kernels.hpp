@@ -29,8 +29,11 @@ __device__ unsigned long long g_stamps[256];
 
 struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.h ...
     double amp_train, amp_cross, p0, p1, p2, p3;
-    double kss_noise;       // ... plus the K(new,new) diagonal term, kept in HBM so that a captured
-                            // graph can be replayed with new hyper-parameters without re-capturing
+    double nug2;            // added to every element of the resident diagonal vector: the nugget**2 term
+                            // of (y_err**2 + floor**2) + nugget**2 (kernel.py:75), so that a new nugget
+                            // costs 8 bytes of upload instead of a new diagonal vector
+    double kss_noise;       // the K(new,new) diagonal term; in HBM (like everything above) so that a
+                            // captured graph is replayed with new hyper-parameters without re-capturing
 };
 
 // v_mfma_f64_16x16x4_f64.  Lane maps (cdna_hip_programming.md 3, checked by
@@ -98,7 +101,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void k_assemble_train(
     double* __restrict__ M, long ld, long sM, const double* __restrict__ x, long sx,
     const double* __restrict__ diag, long sd, const int* __restrict__ ns, const KParams* __restrict__ kpp,
-    int lower_only) {
+    int lower_only, int use_nug2) {
     const int b = blockIdx.z;
     const int col0 = blockIdx.x * 128, row0 = blockIdx.y * 64;
     if (lower_only && col0 > row0 + 63) return;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_assemble_train(
             double e0 = kp.amp_train * exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp));
             double e1 = kp.amp_train * exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp));
             if (i < n) {
-                double dg = kp.amp_train + diag[i];
+                double dg = kp.amp_train + (use_nug2 ? (diag[i] + kp.nug2) : diag[i]);
                 o.x = (c < n) ? ((c == i) ? dg : e0) : 0.;
                 o.y = (c + 1 < n) ? ((c + 1 == i) ? dg : e1) : 0.;
             } else {

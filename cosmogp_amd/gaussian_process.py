@@ -98,7 +98,7 @@ def log_likelihood_gp(y, x_axis, kernel, hyperparameter, nugget, y_err=None, y_m
         return ll
     dev = device if device is not None else _lib.default_device()
     dev.set_data(dim, x_axis, np.ones(n) * resid)
-    ll, _, _, _ = dev.fit(_kparams(dim, hyperparameter), _kernel.diag_term(n, y_err, 0., nugget))
+    ll, _, _, _ = dev.fit(_kparams(dim, hyperparameter, nugget), _kernel.diag_term(n, y_err, 0., 0.))
     return np.array([ll])
 
 
@@ -110,8 +110,10 @@ def _kernel_dim(kernel):
     raise ValueError('kernel must be RBF1D / RBF2D (or rbf_kernel_1d / rbf_kernel_2d)')
 
 
-def _kparams(dim, hyperparameter):
-    return _kernel.kernel_params_1d(hyperparameter) if dim == 1 else _kernel.kernel_params_2d(hyperparameter)
+def _kparams(dim, hyperparameter, nugget=0.):
+    if dim == 1:
+        return _kernel.kernel_params_1d(hyperparameter, nugget)
+    return _kernel.kernel_params_2d(hyperparameter, nugget=nugget)
 
 
 class Gaussian_process(object):
@@ -166,8 +168,9 @@ class Gaussian_process(object):
     def _resid(self, sn):
         return np.asarray(self.y[sn], dtype=np.float64) - self.y0[sn]
 
-    def _diag(self, sn, nugget):
-        return _kernel.diag_term(len(self.y[sn]), self.y_err[sn], 0., nugget)
+    def _diag(self, sn):
+        """y_err**2 + floor**2 (floor = 0); the nugget**2 term travels in kp[6]."""
+        return _kernel.diag_term(len(self.y[sn]), self.y_err[sn], 0., 0.)
 
     def _my_objects(self):
         if self.comm is None:
@@ -193,11 +196,13 @@ class Gaussian_process(object):
         """One cgp_fit for object sn; its coordinates / residual are uploaded only when another
         object (or another GP on the same handle) replaced them."""
         dev = self.device
+        diag = None                       # keep the resident diagonal vector ...
         if self._resident != (dev.generation, sn):
             dev.set_data(self._dim, self.Time[sn], self._resid(sn))
             self._resident = (dev.generation, sn)
+            diag = self._diag(sn)         # ... unless the object was (re)uploaded
         self._factor_token = None
-        out = dev.fit(kp, self._diag(sn, nugget), grid, new_y0, kss_noise)
+        out = dev.fit(kp, diag, grid, new_y0, kss_noise)
         self._factor_token = (dev.generation, sn, kp.tobytes(), float(nugget))
         return out
 
@@ -238,16 +243,24 @@ class Gaussian_process(object):
             log_likelihood = log_likelihood + np.array([v])
         self.log_likelihood = log_likelihood
 
+    def _batch_upload(self, chunk):
+        """Make `chunk` the resident batch of the handle (skipped when it already is)."""
+        dev = self.device
+        token = (dev.batch_generation, tuple(chunk))
+        if getattr(self, '_batch_resident', None) != token:
+            dev.batch_set_data(self._dim, [self.Time[sn] for sn in chunk], [self._resid(sn) for sn in chunk],
+                               [self._diag(sn) for sn in chunk])
+            self._batch_resident = (dev.batch_generation, tuple(chunk))
+
     def _loglik_chol(self, objs, hyperparameter, nugget):
         dev = self.device
-        kp = _kparams(self._dim, hyperparameter)
+        kp = _kparams(self._dim, hyperparameter, nugget)
         if len(objs) == 1:
             return [self._fit_single(objs[0], kp, nugget)[0]]
         out = []
         for chunk in self._batch_chunks(objs):
-            ll, info, _, _ = dev.batch_fit(self._dim, [self.Time[sn] for sn in chunk],
-                                           [self._resid(sn) for sn in chunk],
-                                           [self._diag(sn, nugget) for sn in chunk], kp)
+            self._batch_upload(chunk)      # objects stay in HBM across objective evaluations
+            ll, info, _, _ = dev.batch_fit_resident(kp)
             bad = np.nonzero(info)[0]
             if len(bad):
                 raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
@@ -332,16 +345,14 @@ class Gaussian_process(object):
             self._predict_svd(hyp, nugget, COV)
             return
         dev = self.device
-        kp = _kparams(self._dim, hyp)
+        kp = _kparams(self._dim, hyp, nugget)
         kss_noise = 0. ** 2 + 0. ** 2 + nugget ** 2          # kernel(new_grid, hyp, nugget=...) :357
         objs = self._my_objects()
         shared = not self.as_the_same_time
         if len(objs) > 1 and shared:
             for chunk in self._batch_chunks(objs):
-                _, info, mu, var = dev.batch_fit(self._dim, [self.Time[sn] for sn in chunk],
-                                                 [self._resid(sn) for sn in chunk],
-                                                 [self._diag(sn, nugget) for sn in chunk], kp,
-                                                 xnew=self.new_binning, kss_noise=kss_noise)
+                self._batch_upload(chunk)
+                _, info, mu, var = dev.batch_fit_resident(kp, xnew=self.new_binning, kss_noise=kss_noise)
                 bad = np.nonzero(info)[0]
                 if len(bad):
                     raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'

@@ -39,14 +39,15 @@ def diag_term(n, y_err=None, floor=0., nugget=0.):
     return np.asarray(y_err, dtype=np.float64) ** 2 + floor ** 2 + nugget ** 2
 
 
-def kernel_params_1d(hyperparameter):
-    """kp vector of include/cosmogp_hip.h for RBF1D."""
+def kernel_params_1d(hyperparameter, nugget=0.):
+    """kp vector of include/cosmogp_hip.h for RBF1D; kp[6] = nugget**2 is added on the device to the
+    resident diagonal vector y_err**2 + floor**2 (same left-to-right order as kernel.py:75)."""
     amp = hyperparameter[0] ** 2
-    return np.array([amp, amp, hyperparameter[1] ** 2, 0., 0., 0.], dtype=np.float64)
+    return np.array([amp, amp, hyperparameter[1] ** 2, 0., 0., 0., nugget ** 2], dtype=np.float64)
 
 
-def kernel_params_2d(hyperparameter, sigma2_in_train=None):
-    """kp vector for RBF2D: inv_l built exactly as kernel.py:127-130."""
+def kernel_params_2d(hyperparameter, sigma2_in_train=None, nugget=0.):
+    """kp vector for RBF2D: inv_l built exactly as kernel.py:127-130; kp[6] = nugget**2."""
     if sigma2_in_train is None:
         sigma2_in_train = SIGMA2_IN_TRAIN_2D
     h = hyperparameter
@@ -54,7 +55,7 @@ def kernel_params_2d(hyperparameter, sigma2_in_train=None):
     inv_l *= 1. / (((h[1] ** 2) * (h[2] ** 2)) - h[3] ** 2)
     amp = h[0] ** 2
     return np.array([amp if sigma2_in_train else 1.0, amp,
-                     inv_l[0, 0], inv_l[0, 1], inv_l[1, 0], inv_l[1, 1]], dtype=np.float64)
+                     inv_l[0, 0], inv_l[0, 1], inv_l[1, 0], inv_l[1, 1], nugget ** 2], dtype=np.float64)
 
 
 def _rbf(dim, x, kp, new_x, nugget, floor, y_err, device):

@@ -69,9 +69,9 @@ class build_pull(object):
                         y0 = 0.
                     xs.append(x[keep])
                     rs.append(y[keep] - y0)
-                    ds.append(_kernel.diag_term(n - 1, yerr[keep], 0., self.nugget))
+                    ds.append(_kernel.diag_term(n - 1, yerr[keep], 0., 0.))
                 grids = x.reshape((n, 1) + x.shape[1:])                      # one point per sub-problem
-                _, info, mu, var = dev.batch_fit(dim, xs, rs, ds, _kparams(dim, self.hyperparameters),
+                _, info, mu, var = dev.batch_fit(dim, xs, rs, ds, _kparams(dim, self.hyperparameters, self.nugget),
                                                  xnew=grids, kss_noise=0. ** 2 + 0. ** 2 + self.nugget ** 2,
                                                  xnew_per_object=True)
                 if np.any(info):

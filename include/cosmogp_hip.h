@@ -27,15 +27,18 @@
  *     device workspaces; calls on one handle are serialised by the caller
  *   - no torch / numpy types cross this boundary.
  *
- * Kernel parameters ("kp", 6 doubles), computed by the host exactly as the reference does:
+ * Kernel parameters ("kp", 7 doubles), computed by the host exactly as the reference does:
  *   kp[0] amp_train  multiplies exp() in the train-train matrix
  *                    1D: h0**2 (kernel.py:72); 2D: 1.0 -- the reference omits sigma^2 there
  *                    (kernel.py:146) -- or h0**2 in corrected mode
  *   kp[1] amp_cross  multiplies exp() in the cross matrix: h0**2 (kernel.py:72, :141)
  *   kp[2..5]         1D: kp[2] = h1**2 (kernel.py:72)
  *                    2D: VI = inv_l row-major [VI00, VI01, VI10, VI11] (kernel.py:127-130)
- * The diagonal term (y_err**2 + floor**2 + nugget**2, kernel.py:74-75/:150-151) is passed as a
- * length-n vector `diag` evaluated by the host in the reference's operation order.
+ *   kp[6]            nug2: added on the device to every element of `diag` (0 when unused)
+ * The diagonal term (y_err**2 + floor**2 + nugget**2, kernel.py:74-75/:150-151) is
+ * diag[i] + kp[6] with diag = y_err**2 + floor**2 a length-n vector evaluated by the host: the
+ * reference's left-to-right order (a + b) + c is kept, and an objective evaluation with a new nugget
+ * uploads 8 bytes instead of a vector.  (Callers may also fold everything into `diag`, kp[6] = 0.)
  */
 #ifndef COSMOGP_HIP_H
 #define COSMOGP_HIP_H
@@ -94,7 +97,8 @@ int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resi
 /* Assemble K(kp, diag) on the device, factor it (lower Cholesky, in place) and solve the
  * residual row; optionally, in the same pass, assemble the cross matrix for m new points,
  * solve it and produce the prediction.
- *   diag      n doubles (NULL = zeros)
+ *   diag      n doubles: uploaded and kept resident; NULL = keep the resident vector (zeros right
+ *             after cgp_fit_set_data)
  *   xnew      m points, or NULL (m = 0): log-likelihood only
  *   mean_new  m doubles added to the predicted mean (NULL = 0)       [Gaussian_process.py:335]
  *   kss_noise scalar diagonal term of K(new,new): (0**2 + floor**2 + nugget**2); the device
@@ -125,6 +129,10 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out);
  * (xnew_per_object = 1; leave-one-out of cosmogp/pull.py:75-90) -- may be NULL (m = 0).
  * mean_new: m doubles shared by all objects or NULL.
  * Outputs: loglik[B], info[B] (0 or first bad pivot), mu[B*m], var[B*m] (may be NULL). */
+int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
+                       const double* x, const double* resid, const double* diag);
+/* x == resid == NULL: fit the batch left resident by cgp_batch_set_data (B, dim must match; ns, diag
+ * ignored) -- the form the fit driver uses, one call per objective evaluation. */
 int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
                   const double* x, const double* resid, const double* diag,
                   const double* kp, const double* xnew, int64_t m, int xnew_per_object,

@@ -23,7 +23,7 @@ def _kernel_from_kp(dim, kp):
         if xnew is None:
             k = kp[0] * np.exp(arg)
             idx = np.arange(len(x))
-            k[idx, idx] = kp[0] + (0. if diag is None else diag)
+            k[idx, idx] = kp[0] + ((0. if diag is None else diag) + kp[6])
             return k
         return kp[1] * np.exp(arg)
 
@@ -33,7 +33,9 @@ def _kernel_from_kp(dim, kp):
 class FakeDevice(object):
     def __init__(self):
         self.generation = 0
+        self.batch_generation = 0
         self.calls = []
+        self.diag = None
 
     def rbf(self, dim, x, kp, xnew=None, diag=None):
         return _kernel_from_kp(dim, kp)(x, xnew, diag)
@@ -41,6 +43,7 @@ class FakeDevice(object):
     def set_data(self, dim, x, resid):
         self.generation += 1
         self.dim, self.x, self.r, self.n = dim, np.asarray(x, float), np.asarray(resid, float), len(resid)
+        self.diag = None
         self.calls.append('set_data')
 
     def _one(self, dim, x, r, diag, kp, xnew, mean_new, kss_noise):
@@ -58,8 +61,10 @@ class FakeDevice(object):
 
     def fit(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., want_var=True):
         self.calls.append('fit')
-        self.kp, self.diag = np.array(kp), diag
-        ll, mu, var = self._one(self.dim, self.x, self.r, diag, kp, xnew, mean_new, kss_noise)
+        if diag is not None:
+            self.diag = np.array(diag)          # resident, like the real handle
+        self.kp = np.array(kp)
+        ll, mu, var = self._one(self.dim, self.x, self.r, self.diag, kp, xnew, mean_new, kss_noise)
         return ll, 0., mu, var
 
     def predict(self, xnew, mean_new=None, kss_noise=0., want_cov=False):
@@ -67,7 +72,9 @@ class FakeDevice(object):
         K = kern(self.x, None, self.diag)
         H = kern(self.x, xnew)
         Ki = np.linalg.inv(K)
-        cov = kern(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ Ki @ H.T
+        kp0 = self.kp.copy()
+        kp0[6] = 0.
+        cov = _kernel_from_kp(self.dim, kp0)(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ Ki @ H.T
         mu = H @ Ki @ self.r + (0. if mean_new is None else mean_new)
         return mu, np.diag(cov).copy(), cov if want_cov else None
 
@@ -75,8 +82,22 @@ class FakeDevice(object):
         K = _kernel_from_kp(self.dim, self.kp)(self.x, None, self.diag)
         return [K, np.linalg.cholesky(K), np.linalg.inv(K)][which]
 
+    def batch_set_data(self, dim, xs, resids, diags=None):
+        self.batch_generation += 1
+        self.calls.append('batch_set_data:%d' % len(xs))
+        self._b = (dim, [np.asarray(a, float) for a in xs], [np.asarray(a, float) for a in resids],
+                   None if diags is None else [np.asarray(a, float) for a in diags])
+
+    def batch_fit_resident(self, kp, xnew=None, mean_new=None, kss_noise=0., xnew_per_object=False):
+        dim, xs, resids, diags = self._b
+        return self._batch(dim, xs, resids, diags, kp, xnew, mean_new, kss_noise, xnew_per_object)
+
     def batch_fit(self, dim, xs, resids, diags, kp, xnew=None, mean_new=None, kss_noise=0.,
                   xnew_per_object=False):
+        self.batch_set_data(dim, xs, resids, diags)
+        return self.batch_fit_resident(kp, xnew, mean_new, kss_noise, xnew_per_object)
+
+    def _batch(self, dim, xs, resids, diags, kp, xnew, mean_new, kss_noise, xnew_per_object):
         self.calls.append('batch_fit:%d' % len(xs))
         B = len(xs)
         ll, info = np.zeros(B), np.zeros(B, dtype=np.int32)

@@ -550,3 +550,47 @@ def test_svd_method_optin_routes_to_cholesky_when_pd(cg):
         assert np.all(np.isfinite(gs.Prediction[0]))
     finally:
         gpm.SVD_VIA_CHOLESKY_WHEN_PD = False
+
+
+def test_nobject_fit_with_resident_batch(cg):
+    """gaussian_process_nobject.find_hyperparameters: the objects are uploaded once (resident batch),
+    every objective evaluation sends only the kernel-parameter block; result equals the oracle's
+    Nelder-Mead run (same driver, same objective to 1e-11)."""
+    g = load_golden('loglik_1d')
+    xs, ys, es = objs(g)
+    gp = cg.gaussian_process_nobject(ys, xs, kernel='RBF1D', y_err=es)
+    dev = gp.device
+    gen0 = dev.batch_generation
+    gp.find_hyperparameters(hyperparameter_guess=[0.6, 7.], nugget=True, svd_method=False)
+    assert dev.batch_generation == gen0 + 1                       # one upload for ~100+ evaluations
+    y0 = orc.object_means(ys, xs)
+    hyp, ng = orc.find_hyperparameters(ys, xs, 'RBF1D', [0.6, 7.], es, y0, fit_nugget=True, svd_method=False)
+    np.testing.assert_allclose(gp.hyperparameters, hyp, rtol=1e-3)
+    assert abs(gp.nugget - ng) < 1e-3
+    # the likelihood at the optimum agrees tightly (same objective)
+    gp.compute_log_likelihood(list(hyp) + [ng], svd_method=False)
+    ref = orc.total_log_likelihood(ys, xs, 'RBF1D', hyp, ng, es, y0, svd_method=False)
+    np.testing.assert_allclose(gp.log_likelihood, ref, rtol=1e-11)
+
+
+def test_resident_diag_and_nugget_in_kp(cg):
+    """cgp_fit with diag = NULL keeps the resident vector; kp[6] adds nugget^2 in the reference's order."""
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(91)
+    n = 300
+    x = np.sort(rng.uniform(0, 40., n))
+    e = rng.uniform(0.05, 0.1, n)
+    y = np.sin(x) + e * rng.standard_normal(n)
+    dev = cg.default_device()
+    dev.set_data(1, x, y)
+    hyp = [0.9, 2.2]
+    ll_a = dev.fit(K.kernel_params_1d(hyp, 0.07), K.diag_term(n, e, 0., 0.))[0]      # vector + kp[6]
+    ll_b = dev.fit(K.kernel_params_1d(hyp, 0.07), None)[0]                             # resident vector
+    ll_c = dev.fit(K.kernel_params_1d(hyp, 0.), K.diag_term(n, e, 0., 0.07))[0]       # all in the vector
+    assert ll_a == ll_b == ll_c
+    ref = orc.log_likelihood_gp(y, x, 'RBF1D', hyp, 0.07, y_err=e, svd_method=False)[0]
+    assert abs(ll_a - ref) <= 1e-11 * abs(ref)
+    dev.set_data(1, x, y)                                                              # resets the resident diagonal
+    ll_z = dev.fit(K.kernel_params_1d(hyp, 0.3), None)[0]
+    ref_z = orc.log_likelihood_gp(y, x, 'RBF1D', hyp, 0.3, y_err=None, svd_method=False)[0]
+    assert abs(ll_z - ref_z) <= 1e-11 * abs(ref_z)

@@ -16,10 +16,15 @@ def test_kernel_params_match_reference_expressions():
     kp = K.kernel_params_2d(h)
     vi = orc.inv_l_2d(h)
     assert kp[0] == 1.0 and kp[1] == h[0] ** 2
-    assert np.array_equal(kp[2:], vi.ravel())
+    assert np.array_equal(kp[2:6], vi.ravel()) and kp[6] == 0.
+    assert K.kernel_params_2d(h, nugget=0.3)[6] == 0.3 ** 2
     assert K.kernel_params_2d(h, sigma2_in_train=True)[0] == h[0] ** 2
     kp1 = K.kernel_params_1d([0.7, 6.5])
-    assert kp1[0] == 0.7 ** 2 and kp1[1] == 0.7 ** 2 and kp1[2] == 6.5 ** 2
+    assert kp1[0] == 0.7 ** 2 and kp1[1] == 0.7 ** 2 and kp1[2] == 6.5 ** 2 and kp1.shape == (7,)
+    # (y_err^2 + floor^2) + nugget^2: resident vector + kp[6] reproduce the reference's order
+    e = np.array([0.1, 0.2, 0.3])
+    assert np.array_equal(K.diag_term(3, e, 0.01, 0.) + K.kernel_params_1d([1., 1.], 0.03)[6],
+                          K.diag_term(3, e, 0.01, 0.03))
 
 
 def test_diag_term_order():
