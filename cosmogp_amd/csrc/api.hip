@@ -16,7 +16,7 @@ namespace {
 
 constexpr int NB = CGP_NB;
 #ifndef GEMM_BIG_TILE_THRESHOLD
-#define GEMM_BIG_TILE_THRESHOLD 1000000000L
+#define GEMM_BIG_TILE_THRESHOLD 1000000000L   // in situ the 64x64 form is as fast at every size (profiles/r01_gemm_shapes.log)
 #endif
 #ifndef GEMM_KB_BIG
 #define GEMM_KB_BIG 16
@@ -187,27 +187,39 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
     StageScope sc(h, ST_GEMM);
-    long nr = rows / 128, nc = cols / 128;
-    long tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
         const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
         if (tile_skip == 0) h->gemm_flops += 2.0 * K * elems * B;
     }
+    // Tile shapes (isolated 4096^3 rates, profiles/r01_gemm_shapes.log): 128 x 64 tiles with 8 waves reach
+    // 68 TFLOP/s (2 workgroups per CU), 64 x 64 with four 64 x 16 waves 60; the small form wins when the
+    // update has too few tiles to fill the chip with the large one.
+    const long nt128 = cols / 128;
+    const long tiles_big = (tri ? nt128 * (nt128 + 1) + (rows / 128 - nt128) * (cols / 64) : (rows / 128) * (cols / 64));
     if (bulk_cap > 0 && B == 1 && tile_skip == 0) {
         // bulk form: 128 x 128 tiles, 8 waves, one workgroup per CU (162 VGPRs x 2 waves/SIMD), persistent
         // over the tile list with at most bulk_cap workgroups so that 256 - bulk_cap CUs stay free.
         // Kept for the stream-overlap experiments of DESIGN.md 4.3 (measured 10-15 % slower than the
-        // 64 x 64 form at N = 8192, so no caller passes bulk_cap today).
+        // default forms at N = 8192, so no caller passes bulk_cap today).
+        const long nr = rows / 128, nc = cols / 128;
+        const long tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
         dim3 g((unsigned)std::min<long>(tiles, bulk_cap), 1, 1);
         hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, 0);
+    } else if (tiles_big * B >= (getenv("CGP_BIGTILE") ? atol(getenv("CGP_BIGTILE")) : GEMM_BIG_TILE_THRESHOLD)) {
+        // tile_skip counts 64 x 64 tiles of the leading 128 x 128 diagonal block (3); in this tiling that
+        // block is the first 2 tiles
+        const int skip = tile_skip ? 2 : 0;
+        dim3 g((unsigned)(tiles_big - skip), 1, (unsigned)B);
+        hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+                           (int)K, (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, skip);
     } else {
-        nr = rows / 64; nc = cols / 64;
-        tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
+        const long nr = rows / 64, nc = cols / 64;
+        const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
         if (tiles <= 0) return 0;
         dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<64, 64, 2, 2, GEMM_KB_SMALL>), g, dim3(256), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<64, 64, 1, 4, GEMM_KB_SMALL>), g, dim3(256), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip);
     }
     HIPCHK(hipGetLastError());

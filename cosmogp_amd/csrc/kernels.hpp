@@ -620,8 +620,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
     const int srow = tid / CPR, sch = (tid % CPR) * 2;   // staging: RSTEP rows x CPR chunks of 16 B
-    const int ntri = tri ? nc * (nc + 1) / 2 : 0;
-    const int ntot = ntri + (nr - (tri ? nc : 0)) * nc;
+    // Triangular tile map for TM = RT * TN (RT = 1 or 2): tile row ti of the triangle (ti < nt = nc / RT)
+    // holds the RT (ti + 1) column tiles that touch the lower triangle.
+    constexpr int RT = TM / TN;
+    static_assert(TM == RT * TN && (RT == 1 || RT == 2), "tile shape");
+    const int nt = nc / RT;
+    const int ntri = tri ? RT * nt * (nt + 1) / 2 : 0;
+    const int ntot = ntri + (nr - (tri ? nt : 0)) * nc;
     // Persistent tile loop: a launch with fewer workgroups than tiles walks the tile list with stride
     // gridDim.x (bulk updates are launched with <= 240 workgroups of this 1-per-CU kernel so that some
     // CUs stay free for the latency-critical leaf kernels of the other stream).
@@ -632,14 +637,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
         // run together on one XCD span ~16 tile rows x 8 columns, i.e. 24 shared panels per 128 tiles.
         // (A contiguous chunk per XCD was measured WORSE: +15 % HBM fetch, same time.)
         if (bid < ntri) {
-            int i = (int)((sqrtf(8.f * bid + 1.f) - 1.f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= bid) ++i;
-            while (i * (i + 1) / 2 > bid) --i;
+            int i = (int)((sqrtf(8.f * bid / RT + 1.f) - 1.f) * 0.5f);
+            while (RT * (i + 1) * (i + 2) / 2 <= bid) ++i;
+            while (RT * i * (i + 1) / 2 > bid) --i;
             ti = i;
-            tj = bid - i * (i + 1) / 2;
+            tj = bid - RT * i * (i + 1) / 2;
         } else {
             const int r = bid - ntri;
-            ti = (tri ? nc : 0) + r / nc;
+            ti = (tri ? nt : 0) + r / nc;
             tj = r % nc;
         }
     }

@@ -26,19 +26,19 @@ int main() {
     double* M; hipMalloc(&M, h.size() * 8);
     hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     const int rows = 4096, cols = 4096, K = 4096;
-    run<128, 128, 2, 4, 16, 0>("128x128 8w KB16", M, ld, rows, cols, K);
-    run<128, 128, 2, 4, 16, 1>("128x128 8w KB16 no-global", M, ld, rows, cols, K);
-    run<128, 128, 2, 4, 16, 2>("128x128 8w KB16 no-global no-ldsread", M, ld, rows, cols, K);
-    run<128, 128, 4, 4, 16, 0>("128x128 16w KB16", M, ld, rows, cols, K);
-    run<128, 128, 4, 4, 16, 1>("128x128 16w KB16 no-global", M, ld, rows, cols, K);
-    run<128, 128, 4, 4, 16, 2>("128x128 16w KB16 no-global no-ldsread", M, ld, rows, cols, K);
-    run<128, 128, 2, 4, 32, 0>("128x128 8w KB32", M, ld, rows, cols, K);
-    run<128, 128, 2, 4, 32, 1>("128x128 8w KB32 no-global", M, ld, rows, cols, K);
-    run<64, 64, 2, 2, 16, 0>("64x64 4w KB16", M, ld, rows, cols, K);
-    run<64, 64, 2, 2, 16, 1>("64x64 4w KB16 no-global", M, ld, rows, cols, K);
-    run<128, 64, 2, 2, 16, 0>("128x64 4w KB16", M, ld, rows, cols, K);
-    run<128, 128, 2, 2, 16, 0>("128x128 4w(64x64/wave) KB16", M, ld, rows, cols, K);
-    run<128, 128, 2, 2, 16, 1>("128x128 4w(64x64/wave) KB16 no-global", M, ld, rows, cols, K);
-    run<128, 128, 2, 2, 16, 2>("128x128 4w(64x64/wave) KB16 no-glb no-lds", M, ld, rows, cols, K);
+    run<64, 64, 2, 2, 16, 0>("64x64 4w wave 32x32 (old default)", M, ld, rows, cols, K);
+    run<64, 64, 1, 4, 16, 0>("64x64 4w wave 64x16", M, ld, rows, cols, K);
+    run<64, 64, 2, 4, 16, 0>("64x64 8w wave 32x16", M, ld, rows, cols, K);
+    run<64, 128, 1, 4, 16, 0>("64x128 4w wave 64x32", M, ld, rows, cols, K);
+    run<64, 128, 1, 8, 16, 0>("64x128 8w wave 64x16", M, ld, rows, cols, K);
+    run<128, 64, 2, 4, 16, 0>("128x64 8w wave 64x16", M, ld, rows, cols, K);
+    run<128, 64, 4, 2, 16, 0>("128x64 8w wave 32x32", M, ld, rows, cols, K);
+    run<128, 64, 2, 2, 16, 0>("128x64 4w wave 64x32", M, ld, rows, cols, K);
+    run<128, 64, 1, 4, 16, 0>("128x64 4w wave 128x16", M, ld, rows, cols, K);
+    run<128, 128, 1, 8, 16, 0>("128x128 8w wave 128x16", M, ld, rows, cols, K);
+    run<128, 128, 2, 4, 16, 0>("128x128 8w wave 64x32", M, ld, rows, cols, K);
+    run<128, 128, 2, 8, 16, 0>("128x128 16w wave 64x16", M, ld, rows, cols, K);
+    run<128, 128, 4, 4, 16, 0>("128x128 16w wave 32x32", M, ld, rows, cols, K);
+    run<128, 32, 2, 2, 16, 0>("128x32 4w wave 64x16", M, ld, rows, cols, K);
     return 0;
 }
