@@ -643,7 +643,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
             ti = i;
             tj = bid - RT * i * (i + 1) / 2;
         } else {
-            const int r = bid - ntri;
+            int r = bid - ntri;
+#ifdef CGP_GEMM_XCD2D
+            // experiment (tools/gemm_ablate.hip): 2 x 4 grid of XCDs over the rectangular part, XCD (xr, xc)
+            // owns tile rows = xr (mod 2) and tile columns = xc (mod 4)
+            {
+                const int nrr = nr - (tri ? nt : 0);
+                if ((nrr & 1) == 0 && (nc & 3) == 0) {
+                    const int x = r & 7, loc = r >> 3, xr = x >> 2, xc = x & 3, ncx = nc >> 2;
+                    const int lr_ = loc / ncx, lc_ = loc % ncx;
+                    r = (lr_ * 2 + xr) * nc + lc_ * 4 + xc;
+                }
+            }
+#endif
             ti = (tri ? nt : 0) + r / nc;
             tj = r % nc;
         }

@@ -1,4 +1,7 @@
 // Developer harness: time k_gemm_nt variants in isolation (ablation of global loads / LDS reads).
+#ifdef XCD2D
+#define CGP_GEMM_XCD2D
+#endif
 #include "../cosmogp_amd/csrc/kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -18,27 +21,17 @@ void run(const char* name, double* M, long ld, int rows, int cols, int K) {
     }
     printf("%-44s tiles %5d  %.3f ms  %.1f TF/s\n", name, nr * nc, best, 2.0 * rows * cols * K / (best * 1e-3) / 1e12);
 }
-int main() {
-    const long ld = 8192, R = 8192;
+int main(int argc, char** argv) {
+    const long ld = 8192 + (argc > 4 ? atoi(argv[4]) : 0), R = 12288;
     std::vector<double> h((size_t)R * ld);
     srand(1);
     for (auto& v : h) v = (rand() / (double)RAND_MAX - 0.5) * 1e-3;
     double* M; hipMalloc(&M, h.size() * 8);
     hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    const int rows = 4096, cols = 4096, K = 4096;
-    run<64, 64, 2, 2, 16, 0>("64x64 4w wave 32x32 (old default)", M, ld, rows, cols, K);
+    const int rows = (argc > 1 ? atoi(argv[1]) : 4096), cols = (argc > 2 ? atoi(argv[2]) : 4096), K = (argc > 3 ? atoi(argv[3]) : 4096);
     run<64, 64, 1, 4, 16, 0>("64x64 4w wave 64x16", M, ld, rows, cols, K);
-    run<64, 64, 2, 4, 16, 0>("64x64 8w wave 32x16", M, ld, rows, cols, K);
-    run<64, 128, 1, 4, 16, 0>("64x128 4w wave 64x32", M, ld, rows, cols, K);
-    run<64, 128, 1, 8, 16, 0>("64x128 8w wave 64x16", M, ld, rows, cols, K);
-    run<128, 64, 2, 4, 16, 0>("128x64 8w wave 64x16", M, ld, rows, cols, K);
     run<128, 64, 4, 2, 16, 0>("128x64 8w wave 32x32", M, ld, rows, cols, K);
-    run<128, 64, 2, 2, 16, 0>("128x64 4w wave 64x32", M, ld, rows, cols, K);
-    run<128, 64, 1, 4, 16, 0>("128x64 4w wave 128x16", M, ld, rows, cols, K);
-    run<128, 128, 1, 8, 16, 0>("128x128 8w wave 128x16", M, ld, rows, cols, K);
-    run<128, 128, 2, 4, 16, 0>("128x128 8w wave 64x32", M, ld, rows, cols, K);
-    run<128, 128, 2, 8, 16, 0>("128x128 16w wave 64x16", M, ld, rows, cols, K);
-    run<128, 128, 4, 4, 16, 0>("128x128 16w wave 32x32", M, ld, rows, cols, K);
-    run<128, 32, 2, 2, 16, 0>("128x32 4w wave 64x16", M, ld, rows, cols, K);
+    run<64, 64, 1, 4, 16, 1>("64x64 4w wave 64x16 no-global", M, ld, rows, cols, K);
+    run<128, 64, 4, 2, 16, 1>("128x64 8w wave 32x32 no-global", M, ld, rows, cols, K);
     return 0;
 }
