@@ -137,6 +137,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=4,
+                    help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
+                         'buffers); 1 = strictly one fit at a time')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -153,12 +156,18 @@ def main():
         print('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world),
               file=sys.stderr)
 
+    import threading
     from cosmogp_amd import _lib
     from cosmogp_amd import kernel as K
     dev = _lib.Device(local_rank)
     dev.selftest_mfma()
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
+    nstreams = max(1, args.streams)
+    # Independent fits are the unit of this path (objects, candidates): with several in flight the
+    # latency-bound leaf chain of one fit runs in the gaps of the others' bulk updates.  Every handle has
+    # its own stream and its own copy of the inputs in HBM; each fit is still one full pass.
+    extra_devs = [_lib.Device(local_rank) for _ in range(nstreams - 1)]
 
     # ---- inputs to HBM + one checked fit (also sizes every workspace) -------------------------
     if batched:
@@ -168,6 +177,8 @@ def main():
             return dev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
         ll, info, mu, var = step()
         assert not info.any() and np.all(np.isfinite(mu))
+        for d in extra_devs:
+            d.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
         units_per_step = wl['B']
     elif 'sweep' in wl:
         dev.set_data(wl['dim'], wl['x'], wl['y'])
@@ -175,6 +186,9 @@ def main():
         kps = [K.kernel_params_2d([s_, l_, l_, 0.], sigma2_in_train=True) for s_, l_ in wl['sweep']]
         lls = [dev.fit(kp, diag)[0] for kp in kps]
         assert np.all(np.isfinite(lls))
+        for d in extra_devs:
+            d.set_data(wl['dim'], wl['x'], wl['y'])
+            d.fit(kps[0], diag)
         mu, var = np.array(lls), np.zeros(len(lls))
         units_per_step = len(kps)
     else:
@@ -182,26 +196,47 @@ def main():
         diag = K.diag_term(wl['n'], wl['e'], 0., 0.)
         ll, ld, mu, var = dev.fit(wl['kp'], diag, wl['xnew'], None, 0.)
         assert np.isfinite(ll) and np.all(np.isfinite(mu)) and var.min() > -1e-9
+        for d in extra_devs:
+            d.set_data(wl['dim'], wl['x'], wl['y'])
+            out = d.fit(wl['kp'], diag, wl['xnew'], None, 0.)
+            assert out[0] == ll and np.array_equal(out[2], mu)          # every handle computes the same fit
         units_per_step = 1
 
     def sync_all():
-        dev._lib.cgp_synchronize(dev._h)
+        for d in [dev] + extra_devs:
+            d._lib.cgp_synchronize(d._h)
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_steps(k):
-        # k device-resident fits (or batches of fits) back to back on the handle's stream, then sync:
+    all_devs = [dev] + extra_devs
+
+    def run_on(d, k, offset):
+        # k device-resident fits (or batches of fits) back to back on this handle's stream, then sync:
         # the last cgp_fit / cgp_batch_fit left every input in HBM
         if 'sweep' in wl:
-            # one hyper-parameter set per evaluation: 6 doubles go down, 1 comes back (data resident)
-            for _ in range(k):
-                for kp in kps:
-                    dev.fit(kp, diag)
+            # one hyper-parameter set per evaluation: 7 doubles go down, 1 comes back (data resident)
+            for i in range(k):
+                d.fit(kps[(offset + i) % len(kps)], None)
         elif k > 0:
-            dev.bench_fit(k, stages=False)
+            d.bench_fit(k, stages=False)
+
+    def run_steps(k):
+        # EXACTLY k steps (k * units for the sweep), dealt over the handles; ctypes drops the GIL in the call
+        total = k * (len(kps) if 'sweep' in wl else 1)
+        share = [total // len(all_devs) + (1 if i < total % len(all_devs) else 0) for i in range(len(all_devs))]
+        if len(all_devs) == 1:
+            return run_on(dev, share[0], 0)
+        ths, off = [], 0
+        for d, n_ in zip(all_devs, share):
+            ths.append(threading.Thread(target=run_on, args=(d, n_, off)))
+            off += n_
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
     run_steps(args.warmup)
     sync_all()
@@ -235,6 +270,9 @@ def main():
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64)', launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5))
+        t_one = time.perf_counter()
+        dev.bench_fit(3, stages=False)
+        single_ms = (time.perf_counter() - t_one) * 1e3 / 3
         potrf_ms = st[1] + st[2] + st[3]
         chol_flops = n ** 3 / 3.0
         # the sweep also carries the M+1 tall rows (n^2 (m+1) flops): time share by flops
@@ -242,7 +280,7 @@ def main():
         if traffic is not None:
             roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
                                     'separate rocprofv3 passes, see profiles/')
-        extra = dict(ms_per_fit_events=round(ms_fit, 4),
+        extra = dict(single_fit_latency_ms=round(single_ms, 4), ms_per_fit_events=round(ms_fit, 4),
                      stage_ms=dict(assemble_K=round(st[0], 4), potrf_diag=round(st[1], 4), trsm_panel=round(st[2], 4),
                                    gemm_update=round(st[3], 4), assemble_cross=round(st[4], 4), finish=round(st[5], 4)),
                      sweep_gflops=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),
@@ -259,7 +297,8 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                     config=dict(workload=wl['label'], n=wl['n'], m=wl['m'], dim=wl['dim'],
-                                fits_per_step_per_gpu=units_per_step, parallelism='independent fits, 1 rank per GPU'),
+                                fits_per_step_per_gpu=units_per_step, fits_in_flight_per_gpu=nstreams,
+                                parallelism='independent fits, 1 rank per GPU, %d handles (streams) per GPU' % nstreams),
                     roofline=roof)
         if n_gpus == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(wl)

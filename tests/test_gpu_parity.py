@@ -595,3 +595,25 @@ def test_resident_diag_and_nugget_in_kp(cg):
     ll_z = dev.fit(K.kernel_params_1d(hyp, 0.3), None)[0]
     ref_z = orc.log_likelihood_gp(y, x, 'RBF1D', hyp, 0.3, y_err=None, svd_method=False)[0]
     assert abs(ll_z - ref_z) <= 1e-11 * abs(ref_z)
+
+
+def test_sweep_concurrent_handles(cg):
+    """Hyper-parameter sweep with 4 candidates in flight on 4 handles equals the one-at-a-time sweep
+    bit for bit and the oracle to 1e-11."""
+    from cosmogp_amd import multigpu
+    rng = np.random.default_rng(55)
+    n = 900
+    X = rng.uniform(0., 300., (n, 2))
+    y = np.sin(X[:, 0] / 40.) * np.cos(X[:, 1] / 50.) + 0.1 * rng.standard_normal(n)
+    e = np.full(n, 0.1)
+    gp = cg.gaussian_process_2d(y, X, y_err=e)
+    table = np.array([[s_, l_, l_, 0.] for s_ in (0.7, 1.0, 1.4) for l_ in (20., 35., 60.)])
+    a = multigpu.sweep_log_likelihood(gp, table, streams=4)
+    b = multigpu.sweep_log_likelihood(gp, table, streams=1)
+    assert np.array_equal(a, b)
+    for k in (0, 4, 8):
+        ref = orc.log_likelihood_gp(y, X, 'RBF2D', table[k], 0., y_err=e, svd_method=False)[0]
+        assert abs(a[k] - ref) <= 1e-11 * abs(ref)
+    # the GP object still works afterwards (its resident data were replaced by the pool)
+    gp.compute_log_likelihood(table[1], svd_method=False)
+    assert gp.log_likelihood[0] == a[1]
