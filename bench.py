@@ -137,9 +137,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=4,
+    ap.add_argument('--streams', type=int, default=0,
                     help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
-                         'buffers); 1 = strictly one fit at a time')
+                         'buffers); 1 = strictly one fit at a time; 0 = auto: 4 for single-fit / sweep '
+                         'workloads, 1 for the batched one (its launches already span 128 fits)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -163,7 +164,7 @@ def main():
     dev.selftest_mfma()
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
-    nstreams = max(1, args.streams)
+    nstreams = args.streams if args.streams > 0 else (1 if batched else 4)
     # Independent fits are the unit of this path (objects, candidates): with several in flight the
     # latency-bound leaf chain of one fit runs in the gaps of the others' bulk updates.  Every handle has
     # its own stream and its own copy of the inputs in HBM; each fit is still one full pass.
