@@ -64,6 +64,9 @@ struct cgp_handle {
     std::vector<hipEvent_t> fork_events;
     size_t fork_used = 0;
     bool overlap = false;               // true while capturing: cross-stream hops cost ~1.5 us in a graph
+    hipStream_t cur = nullptr;          // stream the factorisation launches go to (main unless split)
+    int split_mode = 0;                 // 0 merged sweep, 1 factor pass records leaf events, 2 solve pass waits
+    std::vector<hipEvent_t> leaf_events;
     std::string err;
     // single-object state
     Prob P;
@@ -248,19 +251,32 @@ int launch_potrf(cgp_handle* h, Prob& P, long c0, hipStream_t stream) {
     return 0;
 }
 
+hipEvent_t leaf_event(cgp_handle* h, int blk) {
+    while ((int)h->leaf_events.size() <= blk) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->leaf_events.push_back(e);
+    }
+    return h->leaf_events[blk];
+}
+
 // potrf_done: the diagonal block at c0 was already factored by the look-ahead branch of the caller
 int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, bool chol, bool potrf_done = false) {
     const long ld = P.Np;
+    hipStream_t S = h->cur ? h->cur : h->stream;
     if (c1 - c0 == NB) {
         const int blk = (int)(c0 / NB);
-        if (chol && !potrf_done) CHK(launch_potrf(h, P, c0, h->stream));
+        if (chol && !potrf_done) CHK(launch_potrf(h, P, c0, S));
         const long r0 = chol ? c0 + NB : rlo;
+        // split mode: the solve pass of column block blk may start once the factor pass has finished it
+        if (!chol && h->split_mode == 2) HIPCHK(hipStreamWaitEvent(S, leaf_event(h, blk), 0));
         if (R > r0) {
             StageScope sc(h, ST_TRSM);
-            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / 64), 1, P.B), dim3(256), LEAF_LDS, h->stream,
+            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / 64), 1, P.B), dim3(256), LEAF_LDS, S,
                                P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
             HIPCHK(hipGetLastError());
         }
+        if (chol && h->split_mode == 1) HIPCHK(hipEventRecord(leaf_event(h, blk), S));
         return 0;
     }
     const long nb = (c1 - c0) / NB;
@@ -275,16 +291,16 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
         // 128 x 128 diagonal block of the region is updated and factored on the second stream while
         // the main stream applies the rest of the update; the panel solve joins both.
         hipEvent_t e0 = next_fork_event(h), e1 = next_fork_event(h);
-        HIPCHK(hipEventRecord(e0, h->stream));
+        HIPCHK(hipEventRecord(e0, S));
         HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
         CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, NB, NB, mid - c0, true, -1.0, 1.0, h->stream2, 0));
         CHK(launch_potrf(h, P, mid, h->stream2));
         HIPCHK(hipEventRecord(e1, h->stream2));
-        CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, true, -1.0, 1.0, h->stream, 3));
-        HIPCHK(hipStreamWaitEvent(h->stream, e1, 0));
+        CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, true, -1.0, 1.0, S, 3));
+        HIPCHK(hipStreamWaitEvent(S, e1, 0));
         return factor_range(h, P, mid, c1, rlo, R, chol, true);
     }
-    CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0));
+    CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
     return factor_range(h, P, mid, c1, rlo, R, chol, false);
 }
 
@@ -388,6 +404,7 @@ int cgp_destroy(cgp_handle* h) {
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->fork_events) (void)hipEventDestroy(e);
+    for (auto e : h->leaf_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -484,7 +501,26 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
                                   m));
         CHK(put_resid_row(h, P));
     }
-    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    if (h->overlap && getenv("CGP_SPLIT_TALL")) {
+        // experiment: factor K (rows < Np) on the main stream and run the solve pass of the tall rows on the
+        // second stream, column block by column block behind it (leaf events): two dependent sweeps that
+        // can overlap like two independent fits do
+        hipEvent_t e0 = next_fork_event(h), e1 = next_fork_event(h);
+        HIPCHK(hipEventRecord(e0, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
+        const bool ov = h->overlap;
+        h->overlap = false;
+        h->split_mode = 1; h->cur = h->stream;
+        int st = factor_range(h, P, 0, P.Np, 0, P.Np, true);
+        h->split_mode = 2; h->cur = h->stream2;
+        if (st >= 0) st = factor_range(h, P, 0, P.Np, P.Np, P.R, false);
+        h->split_mode = 0; h->cur = nullptr; h->overlap = ov;
+        CHK(st);
+        HIPCHK(hipEventRecord(e1, h->stream2));
+        HIPCHK(hipStreamWaitEvent(h->stream, e1, 0));
+    } else {
+        CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    }
     CHK(launch_finish(h, P, m, true, has_mean));
     return 0;
 }
@@ -510,7 +546,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     cgp_handle::CachedGraph cg;
     cg.key = key;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->overlap = getenv("CGP_OVERLAP") != nullptr;     // opt-in: +1.4 % at N = 8192, nothing at N = 4096
+    h->overlap = getenv("CGP_OVERLAP") != nullptr || getenv("CGP_SPLIT_TALL") != nullptr;   // opt-in experiments
     h->fork_used = 0;
     int st = device_fit_eager(h, P, m, has_mean);
     h->overlap = false;
