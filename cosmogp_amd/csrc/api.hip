@@ -16,7 +16,7 @@ namespace {
 
 constexpr int NB = CGP_NB;
 #ifndef GEMM_BIG_TILE_THRESHOLD
-#define GEMM_BIG_TILE_THRESHOLD 1000000000L   // in situ the 64x64 form is as fast at every size (profiles/r01_gemm_shapes.log)
+#define GEMM_BIG_TILE_THRESHOLD 1024L   // 128x64 form from 1024 tiles on: neutral for one fit at a time, +5 % with 4 in flight
 #endif
 #ifndef GEMM_KB_BIG
 #define GEMM_KB_BIG 16
