@@ -990,38 +990,38 @@ int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs
 
 int cgp_selftest_mfma(cgp_handle* h) {
     CHK(begin_call(h));
-    double A[256], B[256], C[256], D[512], ref[256], ref2[256];
+    double A[256], Bt[256], C[256], D[512], ref[256];
     for (int i = 0; i < 16; ++i)
         for (int j = 0; j < 16; ++j) {
             A[i * 16 + j] = (double)((i * 3 + j * 5) % 7 - 3);
-            B[i * 16 + j] = (double)((i * 7 + j * 2 + 1) % 11 - 5);      // asymmetric
+            Bt[i * 16 + j] = (double)((i * 7 + j * 2 + 1) % 11 - 5);      // asymmetric
             C[i * 16 + j] = (double)(i - 2 * j);
         }
     for (int i = 0; i < 16; ++i)
         for (int j = 0; j < 16; ++j) {
             double s = C[i * 16 + j];
-            for (int k = 0; k < 16; ++k) s += A[i * 16 + k] * B[k * 16 + j];
+            for (int k = 0; k < 16; ++k) s += A[i * 16 + k] * Bt[j * 16 + k];
             ref[i * 16 + j] = s;
-        }
-    for (int i = 0; i < 16; ++i)
-        for (int j = 0; j < 16; ++j) {
-            double s = 0.;
-            for (int k = 0; k < 16; ++k) s += A[i * 16 + k] * ref[k * 16 + j];
-            ref2[i * 16 + j] = s;
         }
     CHK(ensure(h, h->bout, 2048 * sizeof(double)));
     double* d = (double*)h->bout.p;
     HIPCHK(hipMemcpyAsync(d, A, sizeof(A), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + 256, B, sizeof(B), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d + 256, Bt, sizeof(Bt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d + 512, C, sizeof(C), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, h->stream, d, d + 256, d + 512, d + 768);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(D, d + 768, sizeof(D), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 256; ++i) {
-        if (D[i] != ref[i]) return fail(h, 1, "f64 MFMA A/B/D lane map mismatch");
-        if (D[256 + i] != ref2[i]) return fail(h, 2, "f64 MFMA D-as-B chaining mismatch");
-    }
+    for (int i = 0; i < 256; ++i)
+        if (D[i] != ref[i]) return fail(h, 1, "f64 4x4x4 MFMA A/B/D lane map mismatch");
+    // E_blk[i][j] = sum_k A[4 blk + i][k] * D[4 blk + k][j]   (k, j in 0..3: D block rows are the k index)
+    for (int blk = 0; blk < 4; ++blk)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.;
+                for (int k = 0; k < 4; ++k) s += A[(4 * blk + i) * 16 + k] * ref[(4 * blk + k) * 16 + j];
+                if (D[256 + blk * 16 + i * 4 + j] != s) return fail(h, 2, "f64 4x4x4 MFMA D-as-B chaining mismatch");
+            }
     return CGP_OK;
 }
 

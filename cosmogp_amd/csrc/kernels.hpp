@@ -13,7 +13,7 @@
 #include <type_traits>
 
 #define CGP_NB 128          // leaf block of the Cholesky (diagonal block lives in LDS)
-#define CGP_SB 16           // sub-block inside the leaf = MFMA tile edge
+#define CGP_SB 16           // sub-block inside the leaf (pivot block of K3, column tile of K4)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -36,16 +36,6 @@ struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.
                             // captured graph is replayed with new hyper-parameters without re-capturing
 };
 
-// v_mfma_f64_16x16x4_f64.  Lane maps (cdna_hip_programming.md 3, checked by
-// cgp_selftest_mfma with exact integer data):
-//   A operand: lane l holds A[m = l & 15][k = l >> 4]
-//   B operand: lane l holds B[k = l >> 4][n = l & 15]
-//   C/D      : lane l, reg r holds D[m = (l >> 4) + 4 r][n = l & 15]
-// so a D tile is directly the B operand of a following product (reg r <-> k-step r).
-__device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction.  Measured on MI355X
 // (tools/microbench_f64.hip, tools/mfma4_layout.hip): 16-17 cycles issue (~30 flop/clk/SIMD,
 // 68 TFLOP/s chip-wide) against ~105 cycles for the 16x16x4 form (~47 TFLOP/s), dependent
@@ -53,6 +43,8 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
 //   A: lane l holds A_blk[i = l & 3][k = l >> 4],  blk = (l >> 2) & 3
 //   B: lane l holds B_blk[k = l >> 4][j = l & 3]
 //   D: lane l holds D_blk[i = l >> 4][j = l & 3]      (so D_blk is again a B operand of blk)
+// (The 16x16x4 form, whose D layout differs from every other dtype -- cdna_hip_programming.md 3 -- is
+// not used: it sustains only ~47 TFLOP/s.)  cgp_selftest_mfma re-checks these maps with exact integers.
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
@@ -838,17 +830,19 @@ __global__ __launch_bounds__(256) void k_stream_store(double* out, long n2) {
     for (; i < n2; i += (long)gridDim.x * blockDim.x) ((d2*)out)[i] = v;
 }
 
-// D = A B + C on one 16x16x16 product with exact small integers; A, B, C, D row-major 16x16
-__global__ void k_mfma_selftest(const double* A, const double* B, const double* Cin, double* D) {
-    const int lane = threadIdx.x, lr = lane & 15, lq = lane >> 4;
-    d4 acc;
-    for (int r = 0; r < 4; ++r) acc[r] = Cin[(lq + 4 * r) * 16 + lr];
-    for (int kk = 0; kk < 4; ++kk) acc = mfma16(A[lr * 16 + lq + 4 * kk], B[(lq + 4 * kk) * 16 + lr], acc);
-    // second product chained through the result layout: E = A * D (D as B operand)
-    d4 e = {0, 0, 0, 0};
-    for (int kk = 0; kk < 4; ++kk) e = mfma16(A[lr * 16 + lq + 4 * kk], acc[kk], e);
-    for (int r = 0; r < 4; ++r) {
-        D[(lq + 4 * r) * 16 + lr] = acc[r];
-        D[256 + (lq + 4 * r) * 16 + lr] = e[r];
-    }
+// One 16 x 16 x 16 product in the register tiling every kernel uses: D[r][c] = C[r][c] + sum_k A[r][k] Bt[c][k]
+// (A and Bt row-major 16 x 16 with k contiguous, like the LDS stages of K5), exact small integers.
+// Block blk of the wave owns rows 4 blk + (0..3); column group J (cols 4 J + (0..3)) is the same in all
+// blocks.  Also checks that a D block is a valid B operand of the same block (E_blk = A_blk D_blk).
+__global__ void k_mfma_selftest(const double* A, const double* Bt, const double* Cin, double* D) {
+    const int lane = threadIdx.x, lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+    double acc[4];
+    for (int J = 0; J < 4; ++J) acc[J] = Cin[(4 * lb + lq) * 16 + 4 * J + lu];
+    for (int kk = 0; kk < 4; ++kk)
+        for (int J = 0; J < 4; ++J)
+            acc[J] = mfma4(A[lr * 16 + lq + 4 * kk], Bt[(4 * J + lu) * 16 + lq + 4 * kk], acc[J]);
+    for (int J = 0; J < 4; ++J) D[(4 * lb + lq) * 16 + 4 * J + lu] = acc[J];
+    // chained product per block: E_blk (4 x 4) = Ablk (4 x 4, rows 4 blk.., cols 0..3 of A) * D_blk[:, cols of J = 0]
+    double e = mfma4(A[(4 * lb + lu) * 16 + lq], acc[0], 0.);
+    D[256 + lb * 16 + lq * 4 + lu] = e;
 }
