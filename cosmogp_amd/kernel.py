@@ -59,8 +59,10 @@ def kernel_params_2d(hyperparameter, sigma2_in_train=None, nugget=0.):
 
 
 def _rbf(dim, x, kp, new_x, nugget, floor, y_err, device):
-    dev = device if device is not None else _lib.default_device()
     x = np.ascontiguousarray(x, dtype=np.float64)
+    if len(x) == 0 or (new_x is not None and len(new_x) == 0):      # empty inputs: empty result, like NumPy
+        return np.zeros((len(x) if new_x is None else len(new_x), len(x)))
+    dev = device if device is not None else _lib.default_device()
     if new_x is None:
         return dev.rbf(dim, x, kp, diag=diag_term(len(x), y_err, floor, nugget))
     return dev.rbf(dim, x, kp, xnew=np.ascontiguousarray(new_x, dtype=np.float64))

@@ -118,3 +118,14 @@ def test_shard_helpers():
     assert sorted(sum(parts, [])) == list(range(8))
     loads = [costs[p].sum() for p in parts]
     assert max(loads) <= 700 ** 3. + 1e-9 + min(loads)
+
+
+def test_empty_inputs_need_no_device():
+    """Empty point sets give empty matrices (what NumPy broadcasting gives in the reference), without
+    touching the GPU."""
+    x = np.zeros(0)
+    assert cosmogp_amd.rbf_kernel_1d(x, [1., 1.]).shape == (0, 0)
+    assert cosmogp_amd.rbf_kernel_1d(np.linspace(0, 1, 5), [1., 1.], new_x=x).shape == (0, 5)
+    assert cosmogp_amd.rbf_kernel_2d(np.zeros((0, 2)), [1., 1., 1., 0.]).shape == (0, 0)
+    assert orc.rbf_kernel_1d(x, [1., 1.]).shape == (0, 0)
+    assert orc.rbf_kernel_1d(np.linspace(0, 1, 5), [1., 1.], new_x=x).shape == (0, 5)
