@@ -274,6 +274,14 @@ def main():
         t_one = time.perf_counter()
         dev.bench_fit(3, stages=False)
         single_ms = (time.perf_counter() - t_one) * 1e3 / 3
+        # single-fit Cholesky rate (the second half of BASELINE.json's metric): log-likelihood-only fits, i.e.
+        # assemble + blocked Cholesky of the N x N matrix with one residual row, N^3/3 flops per fit
+        dev.fit(wl['kp'], None)
+        dev.bench_fit(2, stages=False)
+        t_c = time.perf_counter()
+        dev.bench_fit(5, stages=False)
+        chol_ms = (time.perf_counter() - t_c) * 1e3 / 5
+        dev.fit(wl['kp'], None, wl['xnew'], None, 0.) if wl['xnew'] is not None else None
         potrf_ms = st[1] + st[2] + st[3]
         chol_flops = n ** 3 / 3.0
         # the sweep also carries the M+1 tall rows (n^2 (m+1) flops): time share by flops
@@ -281,7 +289,10 @@ def main():
         if traffic is not None:
             roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
                                     'separate rocprofv3 passes, see profiles/')
-        extra = dict(single_fit_latency_ms=round(single_ms, 4), ms_per_fit_events=round(ms_fit, 4),
+        extra = dict(single_fit_latency_ms=round(single_ms, 4),
+                     single_fit_cholesky_ms=round(chol_ms, 4),
+                     single_fit_cholesky_gflops=round(n ** 3 / 3.0 / (chol_ms * 1e-3) / 1e9, 1),
+                     ms_per_fit_events=round(ms_fit, 4),
                      stage_ms=dict(assemble_K=round(st[0], 4), potrf_diag=round(st[1], 4), trsm_panel=round(st[2], 4),
                                    gemm_update=round(st[3], 4), assemble_cross=round(st[4], 4), finish=round(st[5], 4)),
                      sweep_gflops=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),

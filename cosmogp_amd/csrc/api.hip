@@ -63,10 +63,15 @@ struct cgp_handle {
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
     std::vector<hipEvent_t> fork_events;
     size_t fork_used = 0;
-    bool overlap = false;               // true while capturing: cross-stream hops cost ~1.5 us in a graph
-    hipStream_t cur = nullptr;          // stream the factorisation launches go to (main unless split)
-    int split_mode = 0;                 // 0 merged sweep, 1 factor pass records leaf events, 2 solve pass waits
-    std::vector<hipEvent_t> leaf_events;
+    // Look-ahead inside a captured graph (cross-stream hop ~1.5 us there): every launch of the
+    // factorisation declares the column blocks it reads and writes; a launch waits for the last writer of
+    // each of them when that writer ran on the other stream (panels are never rewritten, so tracking the
+    // last writer per column block covers RAW and WAW; there is no WAR).
+    struct Tracker {
+        bool active = false;
+        std::vector<hipEvent_t> last;       // per column block: event after its last writer (null = none)
+        std::vector<hipStream_t> owner;     // stream that recorded it
+    } trk;
     std::string err;
     // single-object state
     Prob P;
@@ -251,57 +256,81 @@ int launch_potrf(cgp_handle* h, Prob& P, long c0, hipStream_t stream) {
     return 0;
 }
 
-hipEvent_t leaf_event(cgp_handle* h, int blk) {
-    while ((int)h->leaf_events.size() <= blk) {
-        hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        h->leaf_events.push_back(e);
+// ---- dependency tracker (active only while capturing a graph) -----------------------------------------
+int dep_wait(cgp_handle* h, hipStream_t S, long j0, long j1) {
+    if (!h->trk.active) return 0;
+    hipEvent_t seen = nullptr;
+    for (long j = j0; j < j1; ++j) {
+        hipEvent_t e = h->trk.last[j];
+        if (e && h->trk.owner[j] != S && e != seen) {
+            HIPCHK(hipStreamWaitEvent(S, e, 0));
+            seen = e;
+        }
     }
-    return h->leaf_events[blk];
+    return 0;
 }
 
-// potrf_done: the diagonal block at c0 was already factored by the look-ahead branch of the caller
-int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, bool chol, bool potrf_done = false) {
+int dep_mark(cgp_handle* h, hipStream_t S, long j0, long j1) {
+    if (!h->trk.active) return 0;
+    hipEvent_t e = next_fork_event(h);
+    HIPCHK(hipEventRecord(e, S));
+    for (long j = j0; j < j1; ++j) { h->trk.last[j] = e; h->trk.owner[j] = S; }
+    return 0;
+}
+
+// One piece of the update of a split: C[a:R, a:b] -= A[a:R, c0:mid] A[a:b, c0:mid]^T (lower triangle of the
+// square part), on stream S.
+int gemm_piece(cgp_handle* h, Prob& P, hipStream_t S, long c0, long mid, long a, long b, long R) {
     const long ld = P.Np;
-    hipStream_t S = h->cur ? h->cur : h->stream;
+    CHK(dep_wait(h, S, c0 / NB, mid / NB));      // panels it reads
+    CHK(dep_wait(h, S, a / NB, b / NB));         // region it updates
+    CHK(launch_gemm(h, P.B, P.M + a * ld + a, ld, P.sM, P.M + a * ld + c0, P.M + a * ld + c0, ld, P.sM, R - a, b - a,
+                    mid - c0, true, -1.0, 1.0, S));
+    return dep_mark(h, S, a / NB, b / NB);
+}
+
+// Recursive blocked Cholesky on columns [c0, c1) of P.M.
+//   chol = true : factor; all rows below (down to R, i.e. the tall rows too) are solved/updated
+//   chol = false: L already there; only rows [rlo, R) are solved (W = H L^-T)
+// Every update is one GEMM with the full depth of the finished half, so C traffic is
+// O(N^2 log N) instead of O(N^3 / NB).  With the tracker active (graph capture of a fit) the update of a
+// split is issued in pieces: the next block column on the main stream (it is what the following leaf
+// needs), the remaining columns in doubling chunks on the second stream, in the order the right half will
+// need them; the leaf chain then runs beside the bulk of the update instead of after it.
+int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, bool chol) {
+    const long ld = P.Np;
+    hipStream_t S = h->stream;
     if (c1 - c0 == NB) {
         const int blk = (int)(c0 / NB);
-        if (chol && !potrf_done) CHK(launch_potrf(h, P, c0, S));
+        if (chol) {
+            CHK(dep_wait(h, S, blk, blk + 1));
+            CHK(launch_potrf(h, P, c0, S));
+        }
         const long r0 = chol ? c0 + NB : rlo;
-        // split mode: the solve pass of column block blk may start once the factor pass has finished it
-        if (!chol && h->split_mode == 2) HIPCHK(hipStreamWaitEvent(S, leaf_event(h, blk), 0));
         if (R > r0) {
             StageScope sc(h, ST_TRSM);
             hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / 64), 1, P.B), dim3(256), LEAF_LDS, S,
                                P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
             HIPCHK(hipGetLastError());
         }
-        if (chol && h->split_mode == 1) HIPCHK(hipEventRecord(leaf_event(h, blk), S));
-        return 0;
+        return 0;                                // leaf kernels run on the main stream in order: no mark needed
     }
     const long nb = (c1 - c0) / NB;
     const long mid = c0 + (nb / 2) * NB;
-    CHK(factor_range(h, P, c0, mid, rlo, R, chol, potrf_done));
-    const long rs = chol ? mid : rlo;
-    double* Cp = P.M + rs * ld + mid;
-    const double* Ap = P.M + rs * ld + c0;
-    const double* Bp = P.M + mid * ld + c0;
-    if (chol && h->overlap) {
-        // Look-ahead (inside a captured graph, where a cross-stream dependency costs ~1.5 us): the
-        // 128 x 128 diagonal block of the region is updated and factored on the second stream while
-        // the main stream applies the rest of the update; the panel solve joins both.
-        hipEvent_t e0 = next_fork_event(h), e1 = next_fork_event(h);
-        HIPCHK(hipEventRecord(e0, S));
-        HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
-        CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, NB, NB, mid - c0, true, -1.0, 1.0, h->stream2, 0));
-        CHK(launch_potrf(h, P, mid, h->stream2));
-        HIPCHK(hipEventRecord(e1, h->stream2));
-        CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, true, -1.0, 1.0, S, 3));
-        HIPCHK(hipStreamWaitEvent(S, e1, 0));
-        return factor_range(h, P, mid, c1, rlo, R, chol, true);
+    CHK(factor_range(h, P, c0, mid, rlo, R, chol));
+    if (chol && h->trk.active && c1 - mid >= 2 * NB) {
+        // the panels [c0, mid) were written on the main stream: publish them to the second stream once
+        CHK(dep_mark(h, S, c0 / NB, mid / NB));
+        CHK(gemm_piece(h, P, S, c0, mid, mid, mid + NB, R));                    // near: next block column
+        for (long a = mid + NB, w = NB; a < c1; a += w, w *= 2)                  // far: doubling chunks
+            CHK(gemm_piece(h, P, h->stream2, c0, mid, a, std::min(a + w, c1), R));
+        return factor_range(h, P, mid, c1, rlo, R, chol);
     }
-    CHK(launch_gemm(h, P.B, Cp, ld, P.sM, Ap, Bp, ld, P.sM, R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
-    return factor_range(h, P, mid, c1, rlo, R, chol, false);
+    const long rs = chol ? mid : rlo;
+    if (chol) CHK(dep_wait(h, S, mid / NB, c1 / NB));
+    CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
+                    R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
+    return factor_range(h, P, mid, c1, rlo, R, chol);
 }
 
 template <int DIM>
@@ -404,7 +433,6 @@ int cgp_destroy(cgp_handle* h) {
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->fork_events) (void)hipEventDestroy(e);
-    for (auto e : h->leaf_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -501,25 +529,21 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
                                   m));
         CHK(put_resid_row(h, P));
     }
-    if (h->overlap && getenv("CGP_SPLIT_TALL")) {
-        // experiment: factor K (rows < Np) on the main stream and run the solve pass of the tall rows on the
-        // second stream, column block by column block behind it (leaf events): two dependent sweeps that
-        // can overlap like two independent fits do
-        hipEvent_t e0 = next_fork_event(h), e1 = next_fork_event(h);
+    if (h->trk.active) {
+        h->trk.last.assign(P.Np / NB, nullptr);
+        h->trk.owner.assign(P.Np / NB, nullptr);
+        // fork: the second stream joins the capture behind everything issued so far
+        hipEvent_t e0 = next_fork_event(h);
         HIPCHK(hipEventRecord(e0, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
-        const bool ov = h->overlap;
-        h->overlap = false;
-        h->split_mode = 1; h->cur = h->stream;
-        int st = factor_range(h, P, 0, P.Np, 0, P.Np, true);
-        h->split_mode = 2; h->cur = h->stream2;
-        if (st >= 0) st = factor_range(h, P, 0, P.Np, P.Np, P.R, false);
-        h->split_mode = 0; h->cur = nullptr; h->overlap = ov;
-        CHK(st);
+    }
+    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    if (h->trk.active) {
+        // join: everything the second stream did must be complete before the finish kernel (and the
+        // capture can only end once every forked stream has been joined)
+        hipEvent_t e1 = next_fork_event(h);
         HIPCHK(hipEventRecord(e1, h->stream2));
         HIPCHK(hipStreamWaitEvent(h->stream, e1, 0));
-    } else {
-        CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
     }
     CHK(launch_finish(h, P, m, true, has_mean));
     return 0;
@@ -546,10 +570,10 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     cgp_handle::CachedGraph cg;
     cg.key = key;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->overlap = getenv("CGP_OVERLAP") != nullptr || getenv("CGP_SPLIT_TALL") != nullptr;   // opt-in experiments
+    h->trk.active = getenv("CGP_LOOKAHEAD") != nullptr;      // opt-in: measured slower
     h->fork_used = 0;
     int st = device_fit_eager(h, P, m, has_mean);
-    h->overlap = false;
+    h->trk.active = false;
     hipError_t e = hipStreamEndCapture(h->stream, &cg.graph);
     if (st < 0 || e != hipSuccess || !cg.graph) {
         if (getenv("CGP_DEBUG")) fprintf(stderr, "cgp: graph capture failed (st=%d, %s), eager launches\n", st, hipGetErrorString(e));

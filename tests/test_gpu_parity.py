@@ -478,10 +478,11 @@ def test_c4_batch_1024_lightcurves(cg):
 
 
 def test_eager_graph_lookahead_bit_identical(cg, monkeypatch):
-    """The device-side fit is captured into a hipGraph (default); eager single-stream launches
-    (CGP_NO_GRAPH) and the graph with the opt-in two-stream look-ahead (CGP_OVERLAP) must give
-    bit-identical results (same kernels, same floating-point order).  Each mode uses a fresh handle
-    (graphs are cached)."""
+    """The device-side fit is captured into a hipGraph (default); the graph with the opt-in two-stream
+    look-ahead (CGP_LOOKAHEAD) and eager single-stream launches (CGP_NO_GRAPH) must agree.
+    The look-ahead issues each update in column pieces, so a C element receives exactly the same
+    products in the same order: results are bit-identical.  Each mode uses a fresh handle (graphs are
+    cached)."""
     from cosmogp_amd import kernel as K
     from cosmogp_amd import _lib
     rng = np.random.default_rng(77)
@@ -491,8 +492,8 @@ def test_eager_graph_lookahead_bit_identical(cg, monkeypatch):
     y = np.sin(0.05 * x) + 0.1 * rng.standard_normal(n)
     kp, dg = K.kernel_params_1d([1., 2.]), K.diag_term(n, np.full(n, 0.1), 0., 0.)
     outs = []
-    for env in ({}, {'CGP_OVERLAP': '1'}, {'CGP_NO_GRAPH': '1'}):
-        for k in ('CGP_OVERLAP', 'CGP_NO_GRAPH'):
+    for env in ({}, {'CGP_LOOKAHEAD': '1'}, {'CGP_NO_GRAPH': '1'}):
+        for k in ('CGP_LOOKAHEAD', 'CGP_NO_GRAPH'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
