@@ -18,6 +18,14 @@ constexpr int NB = CGP_NB;
 #ifndef GEMM_BIG_TILE_THRESHOLD
 #define GEMM_BIG_TILE_THRESHOLD 1024L   // 128x64 form from 1024 tiles on: neutral for one fit at a time, +5 % with 4 in flight
 #endif
+#ifndef GEMM_BIG_WM
+#define GEMM_BIG_WM 4
+#define GEMM_BIG_WN 2
+#endif
+#ifndef GEMM_SMALL_WM
+#define GEMM_SMALL_WM 1
+#define GEMM_SMALL_WN 4
+#endif
 #ifndef GEMM_KB_BIG
 #define GEMM_KB_BIG 16
 #endif
@@ -220,14 +228,14 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         // block is the first 2 tiles
         const int skip = tile_skip ? 2 : 0;
         dim3 g((unsigned)(tiles_big - skip), 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<128, 64, GEMM_BIG_WM, GEMM_BIG_WN, GEMM_KB_BIG>), g, dim3(64 * GEMM_BIG_WM * GEMM_BIG_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, skip);
     } else {
         const long nr = rows / 64, nc = cols / 64;
         const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
         if (tiles <= 0) return 0;
         dim3 g((unsigned)tiles, 1, (unsigned)B);
-        hipLaunchKernelGGL((k_gemm_nt<64, 64, 1, 4, GEMM_KB_SMALL>), g, dim3(256), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+        hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip);
     }
     HIPCHK(hipGetLastError());
