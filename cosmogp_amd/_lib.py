@@ -36,7 +36,7 @@ class HipError(RuntimeError):
 _dp = ctypes.POINTER(ctypes.c_double)
 _i64 = ctypes.c_int64
 _lib = None
-_lib_lock = threading.Lock()
+_lib_lock = threading.RLock()
 
 
 def load_library():
@@ -280,12 +280,13 @@ _default = {}
 
 
 def default_device():
-    """Process-wide handle on COSMOGP_DEVICE / LOCAL_RANK (created lazily)."""
+    """Process-wide handle on COSMOGP_DEVICE / LOCAL_RANK (created lazily, thread safe)."""
     key = os.getpid()
-    if key not in _default:
-        _default.clear()
-        _default[key] = Device()
-    return _default[key]
+    with _lib_lock:
+        if key not in _default:
+            _default.clear()
+            _default[key] = Device()
+        return _default[key]
 
 
 _pool = {}
@@ -299,7 +300,8 @@ def device_pool(n, index=None):
     first = default_device() if index is None else None
     idx = first.index if first is not None else index
     key = (os.getpid(), idx)
-    devs = _pool.setdefault(key, [first] if first is not None else [])
-    while len(devs) < n:
-        devs.append(Device(idx))
-    return devs[:n]
+    with _lib_lock:
+        devs = _pool.setdefault(key, [first] if first is not None else [])
+        while len(devs) < n:
+            devs.append(Device(idx))
+        return devs[:n]
