@@ -34,6 +34,11 @@ from .mean import return_mean
 
 REFERENCE_STALE_INDEX = False
 
+#: Objects that cannot share one batched launch sequence (each has its own prediction grid) are fitted
+#: through this many handles at once (separate HIP streams and HBM buffers on the same GPU): the leaf
+#: chain of one fit runs in the gaps of the others.  1 = strictly one after the other.
+FITS_IN_FLIGHT = 4
+
 #: Opt-in (SURVEY.md 7 "hard parts"): when True, calls made with the reference's default
 #: svd_method=True first try the GPU Cholesky path, which equals the SVD pseudo-inverse to ~1e-13
 #: whenever K is positive definite (no singular value <= 1e-15 is dropped), and only fall back to the
@@ -362,6 +367,8 @@ class Gaussian_process(object):
                     self.warning_pf = new_y0
                     self.Prediction[sn] = mu[k] + new_y0
                     self.variance[sn] = var[k]
+        elif len(objs) > 1 and FITS_IN_FLIGHT > 1 and self._device is None:
+            self._predict_pooled(objs, kp, kss_noise)
         else:
             for sn in objs:
                 new_y0 = self._new_y0(sn)
@@ -381,6 +388,34 @@ class Gaussian_process(object):
         if COV:
             self._cov_state = (kp, nugget, kss_noise)
             self.get_covariance_matrix()
+
+    def _predict_pooled(self, objs, kp, kss_noise):
+        """Per-object fits with own grids, FITS_IN_FLIGHT of them in flight on a pool of handles."""
+        import threading
+        devs = _lib.device_pool(min(FITS_IN_FLIGHT, len(objs)))
+        errors = []
+
+        def work(slot):
+            try:
+                for sn in objs[slot::len(devs)]:
+                    new_y0 = self._new_y0(sn)
+                    devs[slot].set_data(self._dim, self.Time[sn], self._resid(sn))
+                    _, _, mu, var = devs[slot].fit(kp, self._diag(sn), self._grid(sn), new_y0, kss_noise)
+                    self.Prediction[sn] = mu
+                    self.variance[sn] = var
+                    self.warning_pf = new_y0
+            except Exception as exc:           # e.g. LinAlgError of one object: re-raised by the caller
+                errors.append(exc)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(devs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        self._resident = None                  # the default handle (pool slot 0) now holds another object
+        self._factor_token = None
+        if errors:
+            raise errors[0]
 
     def get_covariance_matrix(self):
         """self.covariance_matrix = [K(new,new; nugget) - H K^-1 H^T] (Gaussian_process.py:340-361).
