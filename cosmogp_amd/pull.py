@@ -12,7 +12,11 @@ from scipy.stats import norm as normal
 
 from . import _lib
 from . import kernel as _kernel
+import sys
+
 from .gaussian_process import gaussian_process, _kparams
+
+gpm = sys.modules['cosmogp_amd.gaussian_process']      # (the package re-exports a class of that name)
 from .mean import return_mean
 
 
@@ -71,14 +75,21 @@ class build_pull(object):
                     rs.append(y[keep] - y0)
                     ds.append(_kernel.diag_term(n - 1, yerr[keep], 0., 0.))
                 grids = x.reshape((n, 1) + x.shape[1:])                      # one point per sub-problem
-                _, info, mu, var = dev.batch_fit(dim, xs, rs, ds, _kparams(dim, self.hyperparameters, self.nugget),
-                                                 xnew=grids, kss_noise=0. ** 2 + 0. ** 2 + self.nugget ** 2,
-                                                 xnew_per_object=True)
-                if np.any(info):
-                    raise np.linalg.LinAlgError('leave-one-out matrix %d is not positive definite'
-                                                % int(np.nonzero(info)[0][0]))
-                pred = mu[:, 0] + offs
-                pred_var = np.abs(var[:, 0])
+                # the n sub-problems go down in chunks whose padded batch fits the HBM budget
+                np_ = (n - 1 + 127) // 128 * 128
+                per = max(1, int(gpm.BATCH_BYTES_LIMIT // ((np_ + 128) * np_ * 8)))
+                pred, pred_var = np.zeros(n), np.zeros(n)
+                kp = _kparams(dim, self.hyperparameters, self.nugget)
+                for lo in range(0, n, per):
+                    hi = min(n, lo + per)
+                    _, info, mu, var = dev.batch_fit(dim, xs[lo:hi], rs[lo:hi], ds[lo:hi], kp, xnew=grids[lo:hi],
+                                                     kss_noise=0. ** 2 + 0. ** 2 + self.nugget ** 2,
+                                                     xnew_per_object=True)
+                    if np.any(info):
+                        raise np.linalg.LinAlgError('leave-one-out matrix %d is not positive definite'
+                                                    % (lo + int(np.nonzero(info)[0][0])))
+                    pred[lo:hi] = mu[:, 0] + offs[lo:hi]
+                    pred_var[lo:hi] = np.abs(var[:, 0])
             pull = (pred - y)
             pull /= np.sqrt(yerr ** 2 + pred_var + self.nugget ** 2)
             res = pred - y

@@ -272,6 +272,17 @@ def test_pull_golden(cg):
     bs = cg.build_pull([g['y']], [g['x']], g['hyp'], nugget=float(g['nugget']), y_err=[g['e']])
     bs.compute_pull(svd_method=False, substract_mean=True)
     np.testing.assert_allclose(bs.pull, g['pull_submean'], rtol=0, atol=1e-8)
+    # chunked batches (tiny HBM budget: 3 sub-problems per launch sequence) give the same pulls
+    import sys
+    gpm = sys.modules['cosmogp_amd.gaussian_process']
+    saved = gpm.BATCH_BYTES_LIMIT
+    try:
+        gpm.BATCH_BYTES_LIMIT = 3 * (128 + 128) * 128 * 8
+        bc = cg.build_pull([g['y']], [g['x']], g['hyp'], nugget=float(g['nugget']), y_err=[g['e']])
+        bc.compute_pull(svd_method=False)
+    finally:
+        gpm.BATCH_BYTES_LIMIT = saved
+    assert np.array_equal(np.array(bc.pull), np.array(bp.pull))
 
 
 # ----------------------------------------------------------------- fused / batched vs oracle
