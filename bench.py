@@ -284,8 +284,17 @@ def main():
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
-                    kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64)', launches_per_fit=int(launches),
-                    flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5))
+                    kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms', launches_per_fit=int(launches),
+                    flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5),
+                    measured='HIP events around every launch, one fit at a time, eager launches '
+                             '(compare with the rocprofv3 summary of `bench.py --streams 1`)')
+        if st[9] > 0:       # per tile form, to be matched against the per-kernel rows of rocprofv3 --stats
+            roof['by_form'] = {
+                'k_gemm_nt<128,64,4,2,16>': dict(launches_per_fit=int(st[9]), avg_launch_ms=round(st[8] / st[9], 5),
+                                                 achieved=round(st[10] / (st[8] * 1e-3) / 1e12, 3)),
+                'k_gemm_nt<64,64,1,4,16>': dict(launches_per_fit=int(launches - st[9]),
+                                                avg_launch_ms=round((gemm_ms - st[8]) / max(1., launches - st[9]), 5),
+                                                achieved=round((flops - st[10]) / ((gemm_ms - st[8]) * 1e-3) / 1e12, 3))}
         t_one = time.perf_counter()
         dev.bench_fit(3, stages=False)
         single_ms = (time.perf_counter() - t_one) * 1e3 / 3

@@ -259,7 +259,7 @@ class Device(object):
     # ---- measurement ---------------------------------------------------------------
     def bench_fit(self, iters, stages=True):
         ms = ctypes.c_double(0.)
-        st8 = np.zeros(8) if stages else None
+        st8 = np.zeros(12) if stages else None
         self._check(self._lib.cgp_bench_fit(self._h, int(iters), ctypes.byref(ms), _ptr(st8)), 'cgp_bench_fit')
         return ms.value, st8
 

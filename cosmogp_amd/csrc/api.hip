@@ -61,7 +61,7 @@ struct Prob {
     double* scal = nullptr;   // [B][2] loglik, logdet
 };
 
-enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_COUNT };
+enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_GEMM_BIG = 8, ST_COUNT = 12 };
 
 }  // namespace
 
@@ -109,8 +109,8 @@ struct cgp_handle {
     struct Rec { hipEvent_t a, b; int stage; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
-    double gemm_flops = 0.;
-    long gemm_launches = 0;
+    double gemm_flops = 0., gemm_big_flops = 0.;
+    long gemm_launches = 0, gemm_big_launches = 0;
 };
 
 namespace {
@@ -202,11 +202,16 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
                 hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
-    StageScope sc(h, ST_GEMM);
+    const long nt128_ = cols / 128;
+    const long tiles_big_ = (tri ? nt128_ * (nt128_ + 1) + (rows / 128 - nt128_) * (cols / 64) : (rows / 128) * (cols / 64));
+    const bool big_form = bulk_cap == 0 &&
+        tiles_big_ * B >= (getenv("CGP_BIGTILE") ? atol(getenv("CGP_BIGTILE")) : GEMM_BIG_TILE_THRESHOLD);
+    StageScope sc(h, big_form ? ST_GEMM_BIG : ST_GEMM);
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
         const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
         if (tile_skip == 0) h->gemm_flops += 2.0 * K * elems * B;
+        if (big_form) { h->gemm_big_launches++; h->gemm_big_flops += 2.0 * K * elems * B; }
     }
     // Tile shapes (isolated 4096^3 rates, profiles/r01_gemm_shapes.log): 128 x 64 tiles with 8 waves reach
     // 68 TFLOP/s (2 workgroups per CU), 64 x 64 with four 64 x 16 waves 60; the small form wins when the
@@ -223,7 +228,7 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         dim3 g((unsigned)std::min<long>(tiles, bulk_cap), 1, 1);
         hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, 0);
-    } else if (tiles_big * B >= (getenv("CGP_BIGTILE") ? atol(getenv("CGP_BIGTILE")) : GEMM_BIG_TILE_THRESHOLD)) {
+    } else if (big_form) {
         // tile_skip counts 64 x 64 tiles of the leading 128 x 128 diagonal block (3); in this tiling that
         // block is the first 2 tiles
         const int skip = tile_skip ? 2 : 0;
@@ -964,10 +969,10 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (stage_ms) {
-        for (int i = 0; i < 8; ++i) stage_ms[i] = 0.;
+        for (int i = 0; i < 12; ++i) stage_ms[i] = 0.;
         h->profiling = true;
-        h->gemm_flops = 0.;
-        h->gemm_launches = 0;
+        h->gemm_flops = h->gemm_big_flops = 0.;
+        h->gemm_launches = h->gemm_big_launches = 0;
         const int reps = std::min(iters, 3);
         for (int i = 0; i < reps; ++i) CHK(device_fit(h, P, h->last_m, h->last_has_mean));
         h->profiling = false;
@@ -976,12 +981,15 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
             stage_ms[r.stage] += (double)t / reps;
+            if (r.stage == ST_GEMM_BIG) stage_ms[ST_GEMM] += (double)t / reps;    // [3] = both forms
             h->pool.push_back(r.a);
             h->pool.push_back(r.b);
         }
         h->recs.clear();
         stage_ms[6] = (double)h->gemm_launches / reps;
         stage_ms[7] = h->gemm_flops / reps;
+        stage_ms[9] = (double)h->gemm_big_launches / reps;
+        stage_ms[10] = h->gemm_big_flops / reps;
     }
     return CGP_OK;
 }

@@ -143,10 +143,12 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
 
 /* Device-resident timing of the last cgp_fit / cgp_batch_fit: runs `iters` fits (or batches) back to back with
  * inputs already in HBM and no host copies, returns average milliseconds per fit measured
- * with HIP events on the handle's stream.  stage_ms[8] (may be NULL) receives per-stage
+ * with HIP events on the handle's stream.  stage_ms[12] (may be NULL) receives per-stage
  * averages from a second, event-instrumented pass:
  *   [0] assemble K  [1] potrf_diag  [2] trsm  [3] gemm update  [4] assemble cross
- *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit */
+ *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit
+ *   [8] the part of [3] spent in the 128x64-tile form  [9] its launches  [10] its flops  [11] unused
+ * stage_ms must hold 12 doubles. */
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
 
 /* Bare v_mfma_f64_4x4x4_4b_f64 issue loop on every CU: measured fp64 matrix ceiling (TFLOP/s),
