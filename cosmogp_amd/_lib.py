@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_fit_set_data', 'cgp_fit',
-    'cgp_fit_predict', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 
@@ -62,6 +62,7 @@ def load_library():
         lib.cgp_fit_set_data.argtypes = [vp, ctypes.c_int, _dp, _dp, _i64]
         lib.cgp_fit.argtypes = [vp, _dp, _dp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp, _dp]
         lib.cgp_fit_predict.argtypes = [vp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp]
+        lib.cgp_fit_grad.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
         lib.cgp_fit_fetch.argtypes = [vp, ctypes.c_int, _dp]
         lib.cgp_batch_set_data.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp]
         lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
@@ -196,6 +197,17 @@ class Device(object):
                                ctypes.byref(ll), ctypes.byref(ld), _ptr(mu), _ptr(var))
         self._check(st, 'cgp_fit')
         return ll.value, ld.value, mu, var
+
+    def fit_grad(self, kp, diag=None):
+        """Returns (loglik, logdet, sums[5]): the log-likelihood of the resident object and the moment
+        sums of its analytic gradient (include/cosmogp_hip.h, cgp_fit_grad)."""
+        kp = _f64(kp, (7,))
+        dg = None if diag is None else _f64(diag, (self.n,))
+        ll, ld = ctypes.c_double(0.), ctypes.c_double(0.)
+        sums = np.zeros(5)
+        st = self._lib.cgp_fit_grad(self._h, _ptr(kp), _ptr(dg), ctypes.byref(ll), ctypes.byref(ld), _ptr(sums))
+        self._check(st, 'cgp_fit_grad')
+        return ll.value, ld.value, sums
 
     def predict(self, xnew, mean_new=None, kss_noise=0., want_cov=False):
         xnew = _f64(xnew)

@@ -32,7 +32,7 @@ constexpr int NB = CGP_NB;
 #ifndef GEMM_KB_SMALL
 #define GEMM_KB_SMALL 16
 #endif
-constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144 + 4 * 16 * CGP_XLD) * sizeof(double);
+constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144) * sizeof(double);
 
 inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
 
@@ -91,6 +91,7 @@ struct cgp_handle {
     DevBuf bM, bx, br, bdiag, bxnew, bws, bldp, binfo, bns, bmean, bmu, bvar, bscal, bkp;
     DevBuf bC, bout, bns2, bdiag2;            // scratch: square outputs
     DevBuf box, boxn;                         // operator-level scratch
+    DevBuf bgrad;                             // 8 doubles: gradient moment sums
     // batched state
     Prob Q;
     DevBuf qM, qx, qr, qdiag, qxnew, qws, qldp, qinfo, qns, qmean, qmu, qvar, qscal;
@@ -322,7 +323,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
         const long r0 = chol ? c0 + NB : rlo;
         if (R > r0) {
             StageScope sc(h, ST_TRSM);
-            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / 64), 1, P.B), dim3(256), LEAF_LDS, S,
+            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / (16 * CGP_K4_WAVES)), 1, P.B), dim3(64 * CGP_K4_WAVES), LEAF_LDS, S,
                                P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
             HIPCHK(hipGetLastError());
         }
@@ -439,7 +440,7 @@ int cgp_destroy(cgp_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf* all[] = {&h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
-                     &h->box, &h->boxn, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
+                     &h->box, &h->boxn, &h->bgrad, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
                      &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
     for (DevBuf* b : all) free_buf(*b);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -718,6 +719,64 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return CGP_OK;
+}
+
+// Log-likelihood and the moment sums of its analytic gradient (the reference only has
+// the derivative-free fmin of Gaussian_process.py:247).  One sweep factors K and turns Np identity
+// tall rows into W = L^-T and the residual row into z: alpha = W z (the finish kernel's "mu"),
+// K^-1 = W W^T (lower triangle), then K8 reduces (alpha alpha^T - K^-1) against the kernel derivatives.
+int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* loglik, double* logdet, double* sums) {
+    CHK(begin_call(h));
+    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_fit_grad: no data (call cgp_fit_set_data)");
+    if (!kp || !sums) return fail(h, CGP_E_ARG, "cgp_fit_grad: bad argument");
+    Prob& P = h->P;
+    const long tall = P.Np + NB, ld = P.Np;
+    CHK(bind_single(h, tall, false));
+    CHK(upload_kp(h, kp, 0.));
+    if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
+    CHK(ensure(h, h->bmu, tall * sizeof(double)));
+    CHK(ensure(h, h->bvar, tall * sizeof(double)));
+    CHK(ensure(h, h->bgrad, 8 * sizeof(double)));
+    P.diag = (double*)h->bdiag.p;
+    P.mean = nullptr;
+    P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = tall;
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
+    CHK(launch_assemble_train(h, P.dim, 1, P.M, ld, P.sM, P.x, 0, P.diag, 0, P.ns, P.Np, true, true));
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.Np * ld, ld, (int)P.Np);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(P.M + 2 * P.Np * ld, 0, (size_t)NB * ld * sizeof(double), h->stream));
+    CHK(put_resid_row(h, P));
+    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    CHK(launch_finish(h, P, P.Np, true, false));            // mu := alpha = W z; scal := loglik, logdet
+    CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, P.Np, P.Np, P.Np, true,
+                    1.0, 0.0));
+    const dim3 g((unsigned)(P.Np / 128), (unsigned)(P.Np / 64), 1);
+    const int nblocks = (int)(g.x * g.y);
+    CHK(ensure(h, h->bout, (size_t)nblocks * 8 * sizeof(double)));
+    if (P.dim == 1)
+        hipLaunchKernelGGL((k_grad_sums<1>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
+                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p);
+    else
+        hipLaunchKernelGGL((k_grad_sums<2>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
+                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(256), 0, h->stream, (const double*)h->bout.p, nblocks, (double*)h->bgrad.p);
+    HIPCHK(hipGetLastError());
+    double sc[2];
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sums, h->bgrad.p, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (loglik) *loglik = sc[0];
+    if (logdet) *logdet = sc[1];
+    h->factored = (info == 0);
+    h->last_was_batch = false;
+    h->last_m = 0;
+    h->last_has_mean = false;
+    h->last_kss_noise = 0.;
+    return info;
 }
 
 }  // extern "C"

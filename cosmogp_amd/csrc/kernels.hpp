@@ -468,9 +468,11 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
 // layout; a finished X_j goes through a wave-private LDS tile to be re-read as an A operand.
 // L_kk (strictly lower 16x16 tiles) and the T_j^-T blocks are staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------
-#define CGP_XLD 18    // row stride of the wave-private X tile (16 x 16 doubles, padded)
+#ifndef CGP_K4_WAVES
+#define CGP_K4_WAVES 4   // waves (16 panel rows each) per workgroup
+#endif
 
-__global__ __launch_bounds__(256) void k_trsm_panel(
+__global__ __launch_bounds__(64 * CGP_K4_WAVES) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
     long sW, int blk) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -482,8 +484,10 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
     const double* Lg = M + (long)c0 * ld + c0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
-    double* Xs = smem + CGP_NB * CGP_LDA + 8 * 256 + 144 + wave * (16 * CGP_XLD);   // wave-private
-    double* Ap = M + (long)(r0 + blockIdx.x * 64 + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
+    // wave-private 16 x 16 tile, kept in the part of Ls that is never loaded (tiles on/above the diagonal):
+    // rows 16 g .. 16 g + 15 (g = wave / 4), columns 16 + 18 (wave % 4) ..; row stride CGP_LDA
+    double* Xs = Ls + (wave >> 2) * 16 * CGP_LDA + 16 + 18 * (wave & 3);
+    double* Ap = M + (long)(r0 + blockIdx.x * (16 * CGP_K4_WAVES) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
 
     CGP_STAMP(50);
     // This wave's 16 x 128 panel rows in MFMA result layout.  The column slot (J, u) of a 16-wide
@@ -496,27 +500,28 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
         S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
     }
     // L_kk strictly-lower tiles -> LDS (all loads of a batch in flight before the LDS writes)
+    constexpr int K4T = 64 * CGP_K4_WAVES;
 #pragma unroll
-    for (int batch = 0; batch < 4; ++batch) {
+    for (int batch = 0; batch < 1024 / K4T; ++batch) {
         d2 tmp[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = tid + (batch * 8 + k) * 256, r = idx >> 6, c = (idx & 63) * 2;
+            const int idx = tid + (batch * 8 + k) * K4T, r = idx >> 6, c = (idx & 63) * 2;
             tmp[k] = (d2){0., 0.};
             if ((c >> 4) < (r >> 4)) tmp[k] = *(const d2*)(Lg + (long)r * ld + c);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx = tid + (batch * 8 + k) * 256, r = idx >> 6, c = (idx & 63) * 2;
+            const int idx = tid + (batch * 8 + k) * K4T, r = idx >> 6, c = (idx & 63) * 2;
             if ((c >> 4) < (r >> 4)) *(d2*)(Ls + r * CGP_LDA + c) = tmp[k];
         }
     }
     {
-        d2 w[4];
+        d2 w[1024 / K4T];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = *(const d2*)(wsW + 2 * (tid + k * 256));
+        for (int k = 0; k < 1024 / K4T; ++k) w[k] = *(const d2*)(wsW + 2 * (tid + k * K4T));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(d2*)(Ws + 2 * (tid + k * 256)) = w[k];
+        for (int k = 0; k < 1024 / K4T; ++k) *(d2*)(Ws + 2 * (tid + k * K4T)) = w[k];
     }
     __syncthreads();
     CGP_STAMP(51);
@@ -526,13 +531,13 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
         CGP_STAMP(52 + jb);
         wave_lds_fence();
         // S_jb -> LDS (result layout) -> A operand;  X_jb = S_jb * T_jb^-T
-        *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu) = (d2){S[jb][0], S[jb][1]};
-        *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu + 2) = (d2){S[jb][2], S[jb][3]};
+        *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu) = (d2){S[jb][0], S[jb][1]};
+        *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu + 2) = (d2){S[jb][2], S[jb][3]};
         wave_lds_fence();
         double x[4] = {0., 0., 0., 0.};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            d2 a = *(const d2*)(Xs + lr * CGP_XLD + 8 * t + 2 * lq);
+            d2 a = *(const d2*)(Xs + lr * CGP_LDA + 8 * t + 2 * lq);
             const double* w0 = Ws + jb * 256 + (8 * t + 2 * lq) * 16 + 4 * lu;     // B[k][4u + J]
             d2 p0 = *(const d2*)(w0), p1 = *(const d2*)(w0 + 2), p2 = *(const d2*)(w0 + 16), p3 = *(const d2*)(w0 + 18);
             x[0] = mfma4(a.x, p0.x, x[0]); x[1] = mfma4(a.x, p0.y, x[1]);
@@ -544,13 +549,13 @@ __global__ __launch_bounds__(256) void k_trsm_panel(
         *(d2*)(Ap + jb * 16 + 2) = (d2){x[2], x[3]};
         if (jb < 7) {
             wave_lds_fence();
-            *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu) = (d2){x[0], x[1]};
-            *(d2*)(Xs + (4 * lb + lq) * CGP_XLD + 4 * lu + 2) = (d2){x[2], x[3]};
+            *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu) = (d2){x[0], x[1]};
+            *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu + 2) = (d2){x[2], x[3]};
             wave_lds_fence();
             // S_i -= X_jb * L[i][jb]^T  for every later tile i  (B row of slot (J,u) = 16 i + 4 u + J)
             d2 a[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) a[t] = -*(const d2*)(Xs + lr * CGP_XLD + 8 * t + 2 * lq);
+            for (int t = 0; t < 2; ++t) a[t] = -*(const d2*)(Xs + lr * CGP_LDA + 8 * t + 2 * lq);
 #pragma unroll
             for (int i = jb + 1; i < 8; ++i) {
 #pragma unroll
@@ -710,23 +715,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    // nk is even (K is a multiple of 32).  The prefetches are UNCONDITIONAL (the stage index is clamped at
+    // the end of the K loop, the last two are redundant re-loads): with a conditional load the compiler
+    // cannot count the loads in flight and waits for vmcnt(0) before every LDS store, which turns the
+    // two-stages-ahead prefetch into a full memory round trip per stage.
     gload(P0{}, 0);
-    if (nk > 1) gload(P1{}, 1);
+    gload(P1{}, 1);
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads where they are written (see above)
     lstore(P0{}, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         // even stage kt: registers P1 hold stage kt+1, P0 is free
-        if (ABLATE == 0 && kt + 2 < nk) gload(P0{}, kt + 2);
+        if (ABLATE == 0) gload(P0{}, min(kt + 2, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
         compute(0, kt);
-        if (kt + 1 < nk) lstore(P1{}, 1);
+        lstore(P1{}, 1);
         __syncthreads();
-        if (kt + 1 < nk) {
-            // odd stage kt+1: registers P0 hold stage kt+2, P1 is free
-            if (ABLATE == 0 && kt + 3 < nk) gload(P1{}, kt + 3);
-            compute(1, kt + 1);
-            if (kt + 2 < nk) lstore(P0{}, 0);
-            __syncthreads();
-        }
+        // odd stage kt+1: registers P0 hold stage kt+2, P1 is free
+        if (ABLATE == 0) gload(P1{}, min(kt + 3, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, kt + 1);
+        lstore(P0{}, 0);                         // (redundant after the last stage; unconditional on purpose)
+        __syncthreads();
     }
 
     // acc[i][j] at lane l = C[16 i + 4 blk + (l >> 4)][4 j + (l & 3)],  blk = (l >> 2) & 3
@@ -798,6 +808,100 @@ __global__ __launch_bounds__(256) void k_finish(
             scal[b * 2 + 1] = s2;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// K8: moment sums for the analytic gradient of the log marginal likelihood
+//   dlogL/dtheta = 1/2 sum_ij M_ij dK_ij/dtheta,   M = alpha alpha^T - K^-1,  alpha = K^-1 r.
+// With K_ij = amp_train E_ij + delta_ij (diag_i + nug2), E = exp(-q/2), every derivative of the RBF
+// families of kernel.py is a combination of five sums over i, j < n (the host applies the chain rule
+// from the kp parametrisation to the caller's hyperparameters):
+//   S[0] = sum M_ij E_ij      S[1] = sum M_ij E_ij d0^2     S[2] = sum M_ij E_ij d0 d1
+//   S[3] = sum M_ij E_ij d1^2     S[4] = sum_i M_ii
+// Kinv is read from its lower triangle (off-diagonal terms count twice).  64 x 128 tile per
+// workgroup like K1; E is recomputed from the coordinates (no second N x N read).  Partial sums per
+// workgroup go to part[block][8]; k_grad_final adds them in a fixed order (bit-reproducible).
+// ------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_grad_sums(
+    const double* __restrict__ Kinv, long ld, const double* __restrict__ alpha, const double* __restrict__ x,
+    const int* __restrict__ ns, const KParams* __restrict__ kpp, double* __restrict__ part) {
+    const int col0 = blockIdx.x * 128, row0 = blockIdx.y * 64;
+    const int bl = blockIdx.y * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[5] = {0., 0., 0., 0., 0.};
+    __shared__ double rx[64 * 2], ra[64], red[4][5];
+    const int n = ns[0];
+    if (col0 <= row0 + 63 && row0 < n) {
+        const KParams kp = *kpp;
+        if (tid < 64 * DIM) rx[tid] = x[(long)row0 * DIM + tid];
+        if (tid < 64) ra[tid] = alpha[row0 + tid];
+        const int c = col0 + 2 * lane;
+        double ux0, uy0 = 0., ux1, uy1 = 0.;
+        if (DIM == 1) {
+            d2 t = *(const d2*)(x + c);
+            ux0 = t.x; ux1 = t.y;
+        } else {
+            d2 t0 = *(const d2*)(x + 2 * (long)c), t1 = *(const d2*)(x + 2 * (long)c + 2);
+            ux0 = t0.x; uy0 = t0.y; ux1 = t1.x; uy1 = t1.y;
+        }
+        const d2 ac = *(const d2*)(alpha + c);
+        __syncthreads();
+        for (int rr = wave; rr < 64; rr += 4) {
+            const int i = row0 + rr;
+            if (i >= n || c > i) continue;
+            const double vx = rx[rr * DIM], vy = (DIM == 2) ? rx[rr * DIM + 1] : 0., ai = ra[rr];
+            const d2 kv = *(const d2*)(Kinv + (long)i * ld + c);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = c + e;
+                if (j > i || j >= n) continue;
+                const double ux = e ? ux1 : ux0, uy = e ? uy1 : uy0;
+                const double m = ai * (e ? ac.y : ac.x) - (e ? kv.y : kv.x);
+                const double w = (j == i) ? 1. : 2.;
+                const double E = exp(rbf_exp_arg<DIM>(ux, uy, vx, vy, kp));
+                const double d0 = ux - vx, d1 = uy - vy, mE = w * m * E;
+                acc[0] += mE;
+                acc[1] += mE * d0 * d0;
+                acc[2] += mE * d0 * d1;
+                acc[3] += mE * d1 * d1;
+                if (j == i) acc[4] += m;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 5) part[(long)bl * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// out[k] = sum over workgroup partials, fixed order (one workgroup)
+__global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red[4][5];
+    double acc[5] = {0., 0., 0., 0., 0.};
+    for (int b = tid; b < nblocks; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += part[(long)b * 8 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 5) out[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // ------------------------------------------------------------------------------------

@@ -273,10 +273,59 @@ class Gaussian_process(object):
             out.extend(ll.tolist())
         return out
 
-    def find_hyperparameters(self, hyperparameter_guess=None, nugget=False, svd_method=True):
-        """Maximum-likelihood hyperparameters with Nelder-Mead (scipy.optimize.fmin), the
+    def compute_log_likelihood_gradient(self, Hyperparameter):
+        """Log-likelihood (as compute_log_likelihood, Cholesky path) AND its analytic gradient with
+        respect to the entries of `Hyperparameter` (trailing nugget included when self.fit_nugget):
+            d logL / d theta = 1/2 tr((alpha alpha' - K^-1) dK/dtheta),   alpha = K^-1 (y - y0).
+        Extension over the reference, which only has the derivative-free
+        search of Gaussian_process.py:247.  Per object one device call (cgp_fit_grad): factor,
+        alpha, K^-1 and the reduction against the kernel derivatives all stay in HBM; five moment
+        sums come back and kernel.gradient_from_sums_* applies the chain rule.
+        Sets self.log_likelihood (shape (1,)) and self.log_likelihood_gradient; returns the latter."""
+        if self.fit_nugget:
+            Nugget = Hyperparameter[-1]
+            hyperparameter = Hyperparameter[:-1]
+        else:
+            Nugget = self.nugget
+            hyperparameter = Hyperparameter
+        nh = len(hyperparameter)
+        kp = _kparams(self._dim, hyperparameter, Nugget)
+        dev = self.device
+        objs = self._my_objects()
+        rows = np.zeros((len(objs), 2 + nh))
+        for k, sn in enumerate(objs):
+            diag = None
+            if self._resident != (dev.generation, sn):
+                dev.set_data(self._dim, self.Time[sn], self._resid(sn))
+                self._resident = (dev.generation, sn)
+                diag = self._diag(sn)
+            self._factor_token = None
+            ll, _, sums = dev.fit_grad(kp, diag)
+            self._factor_token = (dev.generation, sn, kp.tobytes(), float(Nugget))
+            if self._dim == 1:
+                g = _kernel.gradient_from_sums_1d(hyperparameter, Nugget, sums)
+            else:
+                g = _kernel.gradient_from_sums_2d(hyperparameter, Nugget, sums)
+            rows[k, 0] = ll
+            rows[k, 1:1 + nh] = g[:nh]
+            rows[k, 1 + nh] = g[-1]
+        if self.comm is not None:
+            rows = self.comm.gather_units(rows, self.N_sn)
+        log_likelihood = 0
+        for v in rows[:, 0]:
+            log_likelihood = log_likelihood + np.array([v])
+        self.log_likelihood = log_likelihood
+        grad = rows[:, 1:].sum(axis=0)
+        self.log_likelihood_gradient = grad if self.fit_nugget else grad[:nh]
+        return self.log_likelihood_gradient
+
+    def find_hyperparameters(self, hyperparameter_guess=None, nugget=False, svd_method=True, method=None):
+        """Maximum-likelihood hyperparameters.  method=None: Nelder-Mead (scipy.optimize.fmin), the
         reference's driver (Gaussian_process.py:216-253); every evaluation of the objective is
-        one device call with the data already resident in HBM."""
+        one device call with the data already resident in HBM.  method='L-BFGS-B' (or any
+        scipy.optimize.minimize method that takes a gradient): opt-in gradient-based search on the
+        Cholesky path with the analytic gradient of compute_log_likelihood_gradient (extension;
+        svd_method is ignored there)."""
         if hyperparameter_guess is not None:
             assert len(self.hyperparameters) == len(hyperparameter_guess), 'should be same len'
             self.hyperparameters = hyperparameter_guess
@@ -289,7 +338,18 @@ class Gaussian_process(object):
         self.fit_nugget = bool(nugget)
         if self.fit_nugget:
             start.append(1.)
-        best = fmin(cost, start, disp=False)
+        if method is None:
+            best = fmin(cost, start, disp=False)
+        else:
+            from scipy.optimize import minimize
+
+            def cost_grad(hyper):
+                g = self.compute_log_likelihood_gradient(hyper)
+                return -self.log_likelihood[0], -np.asarray(g, dtype=np.float64)
+
+            res = minimize(cost_grad, np.asarray(start, dtype=np.float64), jac=True, method=method)
+            self.fit_result = res
+            best = res.x
         self.hyperparameters = np.array(self.hyperparameters, dtype=np.float64)
         for i in range(len(self.hyperparameters)):
             self.hyperparameters[i] = np.sqrt(best[i] ** 2)

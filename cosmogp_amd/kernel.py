@@ -58,6 +58,32 @@ def kernel_params_2d(hyperparameter, sigma2_in_train=None, nugget=0.):
                      inv_l[0, 0], inv_l[0, 1], inv_l[1, 0], inv_l[1, 1], nugget ** 2], dtype=np.float64)
 
 
+def gradient_from_sums_1d(hyperparameter, nugget, sums):
+    """Chain rule from the moment sums of cgp_fit_grad to d logL / d [sigma, l, nugget] for RBF1D
+    (K = sigma^2 exp(-d^2 / (2 l^2)) + diag, kernel.py:72-75)."""
+    sig, ell = hyperparameter[0], hyperparameter[1]
+    return np.array([sig * sums[0], 0.5 * sig ** 2 * sums[1] / ell ** 3, nugget * sums[4]])
+
+
+def gradient_from_sums_2d(hyperparameter, nugget, sums, sigma2_in_train=None):
+    """Same for RBF2D, d logL / d [sigma, lx, ly, lxy, nugget].  inv_l = L^-1 with
+    L = [[lx^2, lxy], [lxy, ly^2]] (kernel.py:127-130), so d inv_l = -inv_l dL inv_l.  With the
+    reference's train-train matrix (no sigma^2, kernel.py:146) the likelihood does not depend on sigma."""
+    if sigma2_in_train is None:
+        sigma2_in_train = SIGMA2_IN_TRAIN_2D
+    h = hyperparameter
+    kp = kernel_params_2d(h, sigma2_in_train=sigma2_in_train)
+    vi = np.array([[kp[2], kp[3]], [kp[4], kp[5]]])
+    g_vi = -0.25 * kp[0] * np.array([[sums[1], sums[2]], [sums[2], sums[3]]])        # d logL / d inv_l
+    out = np.zeros(5)
+    out[0] = h[0] * sums[0] if sigma2_in_train else 0.
+    for k, dl in ((1, np.array([[2. * h[1], 0.], [0., 0.]])), (2, np.array([[0., 0.], [0., 2. * h[2]]])),
+                  (3, np.array([[0., 1.], [1., 0.]]))):
+        out[k] = np.sum(g_vi * (-vi.dot(dl).dot(vi)))
+    out[4] = nugget * sums[4]
+    return out
+
+
 def _rbf(dim, x, kp, new_x, nugget, floor, y_err, device):
     x = np.ascontiguousarray(x, dtype=np.float64)
     if len(x) == 0 or (new_x is not None and len(new_x) == 0):      # empty inputs: empty result, like NumPy

@@ -116,6 +116,18 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag,
 int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* mean_new,
                     double kss_noise, double* mu, double* var, double* cov);
 
+/* Log-likelihood of the resident object AND the moment sums of its analytic gradient
+ * (gradient-based alternative to the derivative-free scipy.optimize.fmin of
+ * Gaussian_process.py:247; the likelihood is the one of Gaussian_process.py:68-73).  With
+ * K_ij = kp[0] E_ij + delta_ij (diag_i + kp[6]), E = exp(-q/2), M = alpha alpha' - K^-1:
+ *   sums[0] = sum M_ij E_ij          sums[1] = sum M_ij E_ij d0^2    sums[2] = sum M_ij E_ij d0 d1
+ *   sums[3] = sum M_ij E_ij d1^2     sums[4] = sum_i M_ii            (d = x_j - x_i; 1D: d1 = 0)
+ * so that dlogL/dkp[0] = sums[0]/2, dlogL/dkp[6] = sums[4]/2, 1D: dlogL/dkp[2] = kp[0] sums[1] / (4 kp[2]^2),
+ * 2D: dlogL/dkp[2..5] = -kp[0]/4 * (sums[1], sums[2], sums[2], sums[3]).  The caller applies the chain
+ * rule to its own hyperparameters.  Returns like cgp_fit (> 0: not positive definite). */
+int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag,
+                 double* loglik, double* logdet, double* sums);
+
 /* Lazy attributes of the reference object (kernel_matrix :262, inv_kernel_matrix :325):
  * which = CGP_MAT_K (re-assembled, symmetric), CGP_MAT_L (lower factor, zeros above),
  * CGP_MAT_KINV (explicit inverse from the factor).  out: (n, n) dense. */

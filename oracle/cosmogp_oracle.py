@@ -345,3 +345,44 @@ def fit_predict_cho(kmat, resid, h, kss_diag):
     logdet = 2. * np.sum(np.log(np.diag(c[0])))
     ll = -0.5 * resid @ alpha - 0.5 * n * np.log(2 * np.pi) - 0.5 * logdet
     return mu, var, ll
+
+
+# --------------------------------------------------------------------------
+# Analytic gradient of the log marginal likelihood (checker for cgp_fit_grad).
+# The reference has no gradient (it searches with scipy.optimize.fmin,
+# Gaussian_process.py:247), so there is no golden vector for it: this
+# restatement is pinned by central differences of log_likelihood_gp above,
+# which IS pinned by the reference's goldens (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------
+def log_likelihood_gradient(y, x_axis, kernel, hyperparameter, nugget, y_err=None, y_mean=None,
+                            sigma2_in_train=False):
+    """d logL / d [hyperparameter..., nugget] = 1/2 tr((a a' - K^-1) dK/dtheta), a = K^-1 (y - y_mean),
+    with dK/dtheta written out per hyperparameter of kernel.py:72-75 (1D) / :127-151 (2D)."""
+    x = np.asarray(x_axis, dtype=np.float64)
+    n = len(x)
+    h = np.asarray(hyperparameter, dtype=np.float64)
+    if y_mean is None:
+        y_mean = np.zeros(n)
+    r = np.asarray(y, dtype=np.float64) - np.ones(n) * y_mean
+    if kernel == 'RBF1D':
+        kmat = rbf_kernel_1d(x, h, nugget=nugget, y_err=y_err)
+        d = x[None, :] - x[:, None]
+        e = np.exp(-0.5 * d * d / h[1] ** 2)
+        dks = [2. * h[0] * e, h[0] ** 2 * e * d * d / h[1] ** 3]
+    else:
+        kmat = rbf_kernel_2d(x, h, nugget=nugget, y_err=y_err, sigma2_in_train=sigma2_in_train)
+        vi = inv_l_2d(h)
+        d = x[None, :, :] - x[:, None, :]                       # (n, n, 2)
+        q = np.einsum('ija,ab,ijb->ij', d, vi, d)
+        amp = h[0] ** 2 if sigma2_in_train else 1.
+        e = np.exp(-0.5 * q)
+        dks = [2. * h[0] * e if sigma2_in_train else np.zeros((n, n))]
+        for dl in (np.array([[2. * h[1], 0.], [0., 0.]]), np.array([[0., 0.], [0., 2. * h[2]]]),
+                   np.array([[0., 1.], [1., 0.]])):
+            dvi = -vi.dot(dl).dot(vi)
+            dks.append(amp * e * (-0.5) * np.einsum('ija,ab,ijb->ij', d, dvi, d))
+    dks.append(2. * nugget * np.eye(n))
+    c = _la.cho_factor(kmat, lower=True)
+    alpha = _la.cho_solve(c, r)
+    m = np.outer(alpha, alpha) - _la.cho_solve(c, np.eye(n))
+    return np.array([0.5 * np.sum(m * dk) for dk in dks])

@@ -17,7 +17,7 @@ def _kernel_from_kp(dim, kp):
             d = x[None, :] - other[:, None]
             arg = -0.5 * ((d * d) / kp[2])
         else:
-            vi = kp[2:].reshape(2, 2)
+            vi = kp[2:6].reshape(2, 2)
             dist = orc._mahalanobis_sq_then_sqrt(x, other, vi).T
             arg = -0.5 * dist ** 2
         if xnew is None:
@@ -66,6 +66,26 @@ class FakeDevice(object):
         self.kp = np.array(kp)
         ll, mu, var = self._one(self.dim, self.x, self.r, self.diag, kp, xnew, mean_new, kss_noise)
         return ll, 0., mu, var
+
+    def fit_grad(self, kp, diag=None):
+        """Moment sums of include/cosmogp_hip.h (cgp_fit_grad), from dense NumPy."""
+        self.calls.append('fit_grad')
+        if diag is not None:
+            self.diag = np.array(diag)
+        self.kp = np.array(kp)
+        kern = _kernel_from_kp(self.dim, kp)
+        K = kern(self.x, None, self.diag)
+        _, _, ll = orc.fit_predict_cho(K, self.r, np.zeros((0, len(self.r))), np.zeros(0))
+        Ki = np.linalg.inv(K)
+        a = Ki @ self.r
+        M = np.outer(a, a) - Ki
+        E = (K - np.diag(np.diag(K)) + kp[0] * np.eye(len(K))) / kp[0]
+        X = self.x.reshape(len(K), -1)
+        d0 = X[None, :, 0] - X[:, None, 0]
+        d1 = (X[None, :, 1] - X[:, None, 1]) if self.dim == 2 else np.zeros_like(d0)
+        sums = np.array([np.sum(M * E), np.sum(M * E * d0 * d0), np.sum(M * E * d0 * d1), np.sum(M * E * d1 * d1),
+                         np.trace(M)])
+        return ll, 0., sums
 
     def predict(self, xnew, mean_new=None, kss_noise=0., want_cov=False):
         kern = _kernel_from_kp(self.dim, self.kp)

@@ -14,7 +14,7 @@ int main() {
     hipMalloc(&M, h.size() * 8); hipMalloc(&ws, 32 * 2048 * 8); hipMalloc(&ldp, 256); hipMalloc(&info, 4);
     hipMemset(info, 0, 4);
     hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    size_t lds = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144 + 4 * 16 * CGP_XLD) * 8;
+    size_t lds = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144) * 8;
     hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)k_trsm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     unsigned long long st[256];
