@@ -59,6 +59,14 @@ struct Prob {
     double* mean = nullptr;   // shared, may be null
     double* mu = nullptr; double* var = nullptr; long sOut = 0;
     double* scal = nullptr;   // [B][2] loglik, logdet
+    // Layout of the tall rows: W rows start at wrow0 (default Np), the residual row is zrow (default R-1).
+    // tri_base >= 0: the tall rows from tri_base on are identity rows (W = L^-T is upper triangular: row
+    // tri_base + t stays zero left of column t), so a step that ends at column c only touches rows below
+    // tri_base + c.
+    long wrow0 = -1, zrow = -1, tri_base = -1;
+    long w0() const { return wrow0 >= 0 ? wrow0 : Np; }
+    long zr() const { return zrow >= 0 ? zrow : R - 1; }
+    long rend(long Rfull, long c_end) const { return tri_base >= 0 ? std::min(Rfull, tri_base + c_end) : Rfull; }
 };
 
 enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_GEMM_BIG = 8, ST_COUNT = 12 };
@@ -200,7 +208,7 @@ int leaf_attr_once(cgp_handle* h) {
 // the region are lower-triangular (tile granularity), the rest full.
 int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
                 long ld, long sAB, long rows, long cols, long K, bool tri, double alpha, double beta,
-                hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0) {
+                hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
     const long nt128_ = cols / 128;
@@ -211,14 +219,15 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
         const double elems = tri ? 0.5 * (double)cols * (cols + 1) + (double)(rows - cols) * cols : (double)rows * cols;
-        if (tile_skip == 0) h->gemm_flops += 2.0 * K * elems * B;
-        if (big_form) { h->gemm_big_launches++; h->gemm_big_flops += 2.0 * K * elems * B; }
+        // ktri (K = rows = cols): sum_i (i + 1)(K - i) ~ K^3 / 6 products
+        const double fl = ktri ? 2.0 * ((double)K * K * K / 6.0) * B : 2.0 * K * elems * B;
+        if (tile_skip == 0) h->gemm_flops += fl;
+        if (big_form) { h->gemm_big_launches++; h->gemm_big_flops += fl; }
     }
     // Tile shapes (isolated 4096^3 rates, profiles/r01_gemm_shapes.log): 128 x 64 tiles with 8 waves reach
     // 68 TFLOP/s (2 workgroups per CU), 64 x 64 with four 64 x 16 waves 60; the small form wins when the
     // update has too few tiles to fill the chip with the large one.
-    const long nt128 = cols / 128;
-    const long tiles_big = (tri ? nt128 * (nt128 + 1) + (rows / 128 - nt128) * (cols / 64) : (rows / 128) * (cols / 64));
+    const long tiles_big = tiles_big_;
     if (bulk_cap > 0 && B == 1 && tile_skip == 0) {
         // bulk form: 128 x 128 tiles, 8 waves, one workgroup per CU (162 VGPRs x 2 waves/SIMD), persistent
         // over the tile list with at most bulk_cap workgroups so that 256 - bulk_cap CUs stay free.
@@ -228,21 +237,21 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const long tiles = tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc;
         dim3 g((unsigned)std::min<long>(tiles, bulk_cap), 1, 1);
         hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, GEMM_KB_BIG>), g, dim3(512), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, 0);
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, 0, ktri ? 1 : 0);
     } else if (big_form) {
         // tile_skip counts 64 x 64 tiles of the leading 128 x 128 diagonal block (3); in this tiling that
         // block is the first 2 tiles
         const int skip = tile_skip ? 2 : 0;
         dim3 g((unsigned)(tiles_big - skip), 1, (unsigned)B);
         hipLaunchKernelGGL((k_gemm_nt<128, 64, GEMM_BIG_WM, GEMM_BIG_WN, GEMM_KB_BIG>), g, dim3(64 * GEMM_BIG_WM * GEMM_BIG_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                           (int)K, (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, skip);
+                           (int)K, (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, skip, ktri ? 1 : 0);
     } else {
         const long nr = rows / 64, nc = cols / 64;
         const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
         if (tiles <= 0) return 0;
         dim3 g((unsigned)tiles, 1, (unsigned)B);
         hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip);
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -321,9 +330,10 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             CHK(launch_potrf(h, P, c0, S));
         }
         const long r0 = chol ? c0 + NB : rlo;
-        if (R > r0) {
+        const long Re = P.rend(R, c0 + NB);
+        if (Re > r0) {
             StageScope sc(h, ST_TRSM);
-            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((R - r0) / (16 * CGP_K4_WAVES)), 1, P.B), dim3(64 * CGP_K4_WAVES), LEAF_LDS, S,
+            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((Re - r0) / (16 * CGP_K4_WAVES)), 1, P.B), dim3(64 * CGP_K4_WAVES), LEAF_LDS, S,
                                P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
             HIPCHK(hipGetLastError());
         }
@@ -343,7 +353,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
     const long rs = chol ? mid : rlo;
     if (chol) CHK(dep_wait(h, S, mid / NB, c1 / NB));
     CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
-                    R - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
+                    P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
     return factor_range(h, P, mid, c1, rlo, R, chol);
 }
 
@@ -384,7 +394,7 @@ int launch_finish(cgp_handle* h, Prob& P, long m, bool with_loglik, bool has_mea
     const long blocks = m + (with_loglik ? 1 : 0);
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(k_finish, dim3((unsigned)blocks, 1, P.B), dim3(256), 0, h->stream, P.M, P.Np, P.sM, (int)P.Np,
-                       (int)P.Np, (int)(P.R - 1), (int)m, has_mean ? P.mean : nullptr, (const KParams*)h->bkp.p,
+                       (int)P.w0(), (int)P.zr(), (int)m, has_mean ? P.mean : nullptr, (const KParams*)h->bkp.p,
                        P.ldp, P.sLd, (int)(P.Np / NB), P.ns, P.mu, P.var, P.sOut, P.scal);
     HIPCHK(hipGetLastError());
     return 0;
@@ -497,6 +507,7 @@ int upload_padded(cgp_handle* h, DevBuf& b, const double* src, size_t count, siz
 int bind_single(cgp_handle* h, long tall, bool keep_factor) {
     Prob& P = h->P;
     P.B = 1;
+    P.wrow0 = P.zrow = P.tri_base = -1;
     P.R = P.Np + tall;
     P.sM = P.R * P.Np;
     const size_t need = (size_t)P.R * P.Np * sizeof(double);
@@ -523,7 +534,7 @@ int bind_single(cgp_handle* h, long tall, bool keep_factor) {
 
 int put_resid_row(cgp_handle* h, Prob& P) {
     hipLaunchKernelGGL(k_put_resid_row, dim3((unsigned)((P.Np + 255) / 256), 1, P.B), dim3(256), 0, h->stream, P.M,
-                       P.Np, P.sM, P.R - 1, P.r, P.sr, P.ns);
+                       P.Np, P.sM, P.zr(), P.r, P.sr, P.ns);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -742,15 +753,19 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = tall;
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
     CHK(launch_assemble_train(h, P.dim, 1, P.M, ld, P.sM, P.x, 0, P.diag, 0, P.ns, P.Np, true, true));
-    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.Np * ld, ld, (int)P.Np);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(P.M + 2 * P.Np * ld, 0, (size_t)NB * ld * sizeof(double), h->stream));
+    // tall rows: one block with the residual in its last row, then Np identity rows (triangular sweep)
+    P.zrow = P.Np + NB - 1;
+    P.wrow0 = P.tri_base = P.Np + NB;
+    HIPCHK(hipMemsetAsync(P.M + P.Np * ld, 0, (size_t)NB * ld * sizeof(double), h->stream));
     CHK(put_resid_row(h, P));
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.wrow0 * ld, ld, (int)P.Np);
+    HIPCHK(hipGetLastError());
     CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
     CHK(launch_finish(h, P, P.Np, true, false));            // mu := alpha = W z; scal := loglik, logdet
     CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
-    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, P.Np, P.Np, P.Np, true,
-                    1.0, 0.0));
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.wrow0 * ld, P.M + P.wrow0 * ld, ld, 0, P.Np, P.Np, P.Np,
+                    true, 1.0, 0.0, nullptr, 0, 0, true));
+    P.wrow0 = P.zrow = P.tri_base = -1;
     const dim3 g((unsigned)(P.Np / 128), (unsigned)(P.Np / 64), 1);
     const int nblocks = (int)(g.x * g.y);
     CHK(ensure(h, h->bout, (size_t)nblocks * 8 * sizeof(double)));
@@ -790,10 +805,13 @@ int device_inverse(cgp_handle* h) {
     const long ld = P.Np;
     hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.Np * ld, ld, (int)P.Np);
     HIPCHK(hipGetLastError());
+    P.tri_base = P.Np;                       // W = L^-T is upper triangular: N^3/3 instead of N^3 for the sweep ...
     CHK(factor_range(h, P, 0, P.Np, P.Np, P.R, false));
+    P.tri_base = -1;
     CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
-    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, P.Np, P.Np, P.Np, false,
-                    1.0, 0.0));
+    // ... and N^3/3 instead of 2 N^3 for W W^T (lower triangle, K loop from the tile's first row)
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, P.Np, P.Np, P.Np, true,
+                    1.0, 0.0, nullptr, 0, 0, true));
     return 0;
 }
 
@@ -824,7 +842,7 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out) {
     if (which == CGP_MAT_L) return square_to_host(h, P.M, P.Np, P.n, 1, out);
     if (which == CGP_MAT_KINV) {
         CHK(device_inverse(h));
-        return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 0, out);
+        return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 2, out);
     }
     return fail(h, CGP_E_ARG, "cgp_fit_fetch: unknown matrix id");
 }
@@ -863,7 +881,7 @@ int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
     if (logdet_out) *logdet_out = ld_sum;
     h->factored = true;
     CHK(device_inverse(h));
-    return square_to_host(h, (double*)h->bC.p, P.Np, n, 0, inv_out);
+    return square_to_host(h, (double*)h->bC.p, P.Np, n, 2, inv_out);
 }
 
 int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xnew, int64_t m, const double* kp,

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64 * CGP_K4_WAVES) void k_trsm_panel(
 template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
-    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip) {
+    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -657,8 +657,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
             tj = r % nc;
         }
     }
-    const double* Ag = A + (long)(ti * TM) * ld;
-    const double* Bg = B + (long)(tj * TN) * ld;
+    // ktri: A and B are rows of an upper-triangular matrix (row t is zero left of column t, W = L^-T of
+    // the explicit inverse): the products of tile row ti vanish for k < ti * TM, the K loop starts there
+    const int kstart = ktri ? ti * TM : 0;
+    const double* Ag = A + (long)(ti * TM) * ld + kstart;
+    const double* Bg = B + (long)(tj * TN) * ld + kstart;
 
     double acc[MT][NJ];
 #pragma unroll
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     // Global -> registers two stages ahead, registers -> LDS one stage ahead: a load has two
     // full stages of MFMA work to land (thin K = 128 updates are otherwise latency-bound).
     d2 ra[2][PA], rb[2][PB];
-    const int nk = K / KB;
+    const int nk = (K - kstart) / KB;
     auto gload = [&](auto par, int kt) {
         constexpr int P = decltype(par)::value;
         const int k1 = kt * KB + sch;

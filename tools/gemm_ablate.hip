@@ -15,7 +15,7 @@ void run(const char* name, double* M, long ld, int rows, int cols, int K) {
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL((k_gemm_nt<TM, TN, WM, WN, KB, AB>), dim3(nr * nc), dim3(64 * WM * WN), 0, 0, C, ld, 0L, M,
-                           M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0);
+                           M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }

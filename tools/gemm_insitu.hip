@@ -44,7 +44,7 @@ void run(const char* name, double* M, long ld, const std::vector<Upd>& us) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
             hipLaunchKernelGGL((k_gemm_nt<TM, TN, WM, WN, KB, AB>), dim3(tiles), dim3(64 * WM * WN), 0, 0, M + u.a * ld + u.a, ld, 0L,
-                               M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0);
+                               M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
@@ -76,9 +76,9 @@ int main(int argc, char** argv) {
         hipEventRecord(e0, 0);
         for (int rep = 0; rep < 20; ++rep) {
             if (atoi(argv[4]) == 0)
-                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0);
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
             else
-                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 1>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0);
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 1>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
         }
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
