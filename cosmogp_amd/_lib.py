@@ -19,7 +19,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 #: every symbol include/cosmogp_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
-    'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_fit_set_data', 'cgp_fit',
+    'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
     'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
@@ -59,6 +59,9 @@ def load_library():
         lib.cgp_synchronize.argtypes = [vp]
         lib.cgp_rbf.argtypes = [vp, ctypes.c_int, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64]
         lib.cgp_cholesky_inverse.argtypes = [vp, _dp, _i64, _i64, _dp, _dp]
+        lib.cgp_svd_inverse.argtypes = [vp, _dp, _i64, _i64, ctypes.c_double, _dp, _dp, ctypes.POINTER(_i64)]
+        lib.cgp_fit_svd.argtypes = [vp, _dp, _dp, _dp, _i64, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp,
+                                    ctypes.POINTER(_i64), _dp, _dp, _dp]
         lib.cgp_fit_set_data.argtypes = [vp, ctypes.c_int, _dp, _dp, _i64]
         lib.cgp_fit.argtypes = [vp, _dp, _dp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp, _dp]
         lib.cgp_fit_predict.argtypes = [vp, _dp, _i64, _dp, ctypes.c_double, _dp, _dp, _dp]
@@ -167,6 +170,19 @@ class Device(object):
         self._check(st, 'cgp_cholesky_inverse')
         return inv, ld.value
 
+    def svd_inverse(self, K, thresh=1e-15):
+        """(pseudo-inverse, logdet, n_dropped) of a symmetric matrix by the device eigensolver."""
+        K = _f64(K)
+        n = K.shape[0]
+        if K.ndim != 2 or K.shape[1] != n:
+            raise ValueError('expected a square matrix')
+        inv = np.empty((n, n))
+        ld, nd = ctypes.c_double(0.), _i64(0)
+        st = self._lib.cgp_svd_inverse(self._h, _ptr(K), n, n, float(thresh), _ptr(inv), ctypes.byref(ld),
+                                       ctypes.byref(nd))
+        self._check(st, 'cgp_svd_inverse')
+        return inv, ld.value, nd.value
+
     # ---- fused level ---------------------------------------------------------------
     def set_data(self, dim, x, resid):
         x = _f64(x)
@@ -197,6 +213,28 @@ class Device(object):
                                ctypes.byref(ll), ctypes.byref(ld), _ptr(mu), _ptr(var))
         self._check(st, 'cgp_fit')
         return ll.value, ld.value, mu, var
+
+    def fit_svd(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., thresh=1e-15, want_cov=False):
+        """The fit by the reference's svd_method=True algorithm, on the device (cgp_fit_svd).
+        Returns (loglik, logdet, n_dropped, mu, var, cov)."""
+        kp = _f64(kp, (7,))
+        dg = None if diag is None else _f64(diag, (self.n,))
+        ll, ld, nd = ctypes.c_double(0.), ctypes.c_double(0.), _i64(0)
+        if xnew is None:
+            st = self._lib.cgp_fit_svd(self._h, _ptr(kp), _ptr(dg), None, 0, None, float(kss_noise), float(thresh),
+                                       ctypes.byref(ll), ctypes.byref(ld), ctypes.byref(nd), None, None, None)
+            self._check(st, 'cgp_fit_svd')
+            return ll.value, ld.value, nd.value, None, None, None
+        xnew = _f64(xnew)
+        m = xnew.shape[0]
+        mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
+        mu, var = np.empty(m), np.empty(m)
+        cov = np.empty((m, m)) if want_cov else None
+        st = self._lib.cgp_fit_svd(self._h, _ptr(kp), _ptr(dg), _ptr(xnew), m, _ptr(mn), float(kss_noise),
+                                   float(thresh), ctypes.byref(ll), ctypes.byref(ld), ctypes.byref(nd), _ptr(mu),
+                                   _ptr(var), _ptr(cov))
+        self._check(st, 'cgp_fit_svd')
+        return ll.value, ld.value, nd.value, mu, var, cov
 
     def fit_grad(self, kp, diag=None):
         """Returns (loglik, logdet, sums[5]): the log-likelihood of the resident object and the moment

@@ -1,0 +1,322 @@
+// Device symmetric eigensolver for the reference's svd_method=True route (cosmogp/inv_matrix.py:4-18:
+// SVD pseudo-inverse with singular values <= 1e-15 dropped).  For the symmetric K of this path the SVD
+// is the eigen-decomposition (s = |lambda|, U = V sign(lambda)), so
+//     pinv = sum_{|lambda_p| > thr} v_p v_p' / lambda_p ,   logdet = sum log |lambda_p| .
+//
+// Algorithm: two-sided BLOCK JACOBI.  K (Np x Np, both triangles, identity-padded) is cut into
+// nb = Np / 32 block rows/columns; a round of the round-robin tournament pairs all blocks (nb / 2
+// disjoint pairs), and for every pair (I, J)
+//   E1  k_jac_inner : the 64 x 64 pivot matrix S = K[IJ, IJ] is diagonalised completely in LDS by
+//                     cyclic Jacobi with the parallel ordering (63 steps x 32 disjoint rotations per
+//                     sweep), Q accumulated in LDS                       -> Q_pair (64 x 64)
+//   E2  k_jac_apply<0>: K[IJ, :] <- Q' K[IJ, :]      (all pairs: disjoint rows)
+//   E3  k_jac_apply<1>: K[:, IJ] <- K[:, IJ] Q  and  V[:, IJ] <- V[:, IJ] Q   (disjoint columns)
+// nb - 1 rounds = one sweep; sweeps repeat until no rotation larger than tol = eps ||K||_F was needed.
+// E2 / E3 are thin (depth 64) updates, HBM/L2-bound: fp64 VALU FMAs from LDS-staged 64 x 64 tiles (the
+// vector and matrix fp64 peaks of this part are equal; MFMA would buy nothing at depth 64).
+// Rotations with |s_pq| <= tol are skipped, so eigenvalues carry an absolute error of a few eps ||K||,
+// like LAPACK's; modes at that noise level (numerically singular K) come out smaller than dgesdd's
+// and are dropped by the same 1e-15 test the reference applies (documented in DESIGN.md).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+
+#define JB 32            // block size
+#define JP 64            // pivot matrix size (two blocks)
+#define JLD 66           // LDS row stride (doubles): 16-B aligned rows, column walks spread over banks
+
+struct JacStat {
+    double fro;          // ||K||_F at the start
+    double tol;          // rotation threshold (absolute)
+    int rotations;       // pivot matrices that needed at least one rotation in the current sweep
+    int pad;
+};
+
+// ||K||_F and the threshold; one workgroup (K is read once, N^2 doubles)
+__global__ __launch_bounds__(1024) void k_jac_norm(const double* __restrict__ K, long ld, int Np, double tol_factor,
+                                                   JacStat* __restrict__ st) {
+    __shared__ double red[16];
+    double s = 0.;
+    const long tot = (long)Np * Np;
+    for (long idx = threadIdx.x; idx < tot; idx += 1024) {
+        const long r = idx / Np, c = idx - r * Np;
+        const double v = K[r * ld + c];
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        st->fro = sqrt(t);
+        st->tol = tol_factor * 2.220446049250313e-16 * sqrt(t);
+        st->rotations = 0;
+    }
+}
+
+__global__ void k_jac_identity(double* __restrict__ V, long ld, int Np) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)Np * Np;
+    for (; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / Np, c = idx - r * Np;
+        V[r * ld + c] = (r == c) ? 1. : 0.;
+    }
+}
+
+__device__ __forceinline__ int jac_row(int I, int J, int r) { return r < JB ? I * JB + r : J * JB + (r - JB); }
+
+// E1: one workgroup per pair.  pairs[2 k], pairs[2 k + 1] = block indices.  Q_pair -> Qws[k][64][64]
+// (row-major, Q[s][c]); flags[k] = 1 when any rotation was applied (0: Q = I, the updates skip the pair).
+__global__ __launch_bounds__(256) void k_jac_inner(const double* __restrict__ K, long ld, const int* __restrict__ pairs,
+                                                   double* __restrict__ Qws, int* __restrict__ flags,
+                                                   JacStat* __restrict__ st, int max_sweeps) {
+    __shared__ __attribute__((aligned(16))) double S[JP * JLD];
+    __shared__ __attribute__((aligned(16))) double Q[JP * JLD];
+    __shared__ double rc[32], rs[32];
+    __shared__ int rp[32], rq[32];
+    __shared__ int any_sweep, any_total;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int I = pairs[2 * k], J = pairs[2 * k + 1];
+    const double tol = st->tol;
+    for (int idx = tid; idx < JP * JP; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        S[r * JLD + c] = K[(long)jac_row(I, J, r) * ld + jac_row(I, J, c)];
+        Q[r * JLD + c] = (r == c) ? 1. : 0.;
+    }
+    if (tid == 0) any_total = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) any_sweep = 0;
+        __syncthreads();
+        for (int step = 0; step < JP - 1; ++step) {
+            if (tid < 32) {
+                // circle method on 64 players: player 63 stays, the others rotate
+                int p, q;
+                if (tid == 0) { p = step; q = JP - 1; }
+                else { p = (step + tid) % (JP - 1); q = (step - tid + (JP - 1)) % (JP - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                const double apq = S[p * JLD + q];
+                double c = 1., s = 0.;
+                if (fabs(apq) > tol) {
+                    const double tau = (S[q * JLD + q] - S[p * JLD + p]) / (2. * apq);
+                    const double t = (tau >= 0. ? 1. : -1.) / (fabs(tau) + sqrt(1. + tau * tau));
+                    c = 1. / sqrt(1. + t * t);
+                    s = t * c;
+                    any_sweep = 1;
+                }
+                rc[tid] = c; rs[tid] = s; rp[tid] = p; rq[tid] = q;
+            }
+            __syncthreads();
+            // rows: S <- J' S
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int item = tid + 256 * i, pr = item >> 6, col = item & 63;
+                const double s = rs[pr];
+                if (s != 0.) {
+                    const double c = rc[pr];
+                    const int p = rp[pr], q = rq[pr];
+                    const double a = S[p * JLD + col], b = S[q * JLD + col];
+                    S[p * JLD + col] = c * a - s * b;
+                    S[q * JLD + col] = s * a + c * b;
+                }
+            }
+            __syncthreads();
+            // columns: S <- S J,  Q <- Q J
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int item = tid + 256 * i, pr = item >> 6, row = item & 63;
+                const double s = rs[pr];
+                if (s != 0.) {
+                    const double c = rc[pr];
+                    const int p = rp[pr], q = rq[pr];
+                    double a = S[row * JLD + p], b = S[row * JLD + q];
+                    S[row * JLD + p] = c * a - s * b;
+                    S[row * JLD + q] = s * a + c * b;
+                    a = Q[row * JLD + p]; b = Q[row * JLD + q];
+                    Q[row * JLD + p] = c * a - s * b;
+                    Q[row * JLD + q] = s * a + c * b;
+                }
+            }
+            __syncthreads();
+        }
+        const int more = any_sweep;
+        __syncthreads();
+        if (!more) break;
+        if (tid == 0) any_total = 1;
+    }
+    __syncthreads();
+    const int rotated = any_total;
+    if (rotated) {
+        double* Qo = Qws + (long)k * JP * JP;
+        for (int idx = tid; idx < JP * JP; idx += 256) Qo[idx] = Q[(idx >> 6) * JLD + (idx & 63)];
+    }
+    if (tid == 0) {
+        flags[k] = rotated;
+        if (rotated) atomicAdd(&st->rotations, 1);
+    }
+}
+
+// E2 (MODE 0): X[IJ, c0:c0+64] <- Q' X[IJ, c0:c0+64]        grid (Np / 64, npairs, 1),     X = K
+// E3 (MODE 1): X[r0:r0+64, IJ] <- X[r0:r0+64, IJ] Q           grid (Np / 64, npairs, 2),     X = K, V
+// Both are  Y[a][b] = sum_s A[s][a] B[s][b]  on LDS tiles:  MODE 0: A = Q, B = X;  MODE 1: A = X^T, B = Q.
+// Thread (ta, tb) owns the 4 x 4 outputs a = 4 ta.., b = 4 tb...
+template <int MODE>
+__global__ __launch_bounds__(256) void k_jac_apply(double* __restrict__ X0, double* __restrict__ X1, long ld,
+                                                   const int* __restrict__ pairs, const double* __restrict__ Qws,
+                                                   const int* __restrict__ flags) {
+    const int k = blockIdx.y;
+    if (!flags[k]) return;
+    __shared__ __attribute__((aligned(16))) double As[JP * JLD];
+    __shared__ __attribute__((aligned(16))) double Bs[JP * JLD];
+    double* X = blockIdx.z ? X1 : X0;
+    const int I = pairs[2 * k], J = pairs[2 * k + 1];
+    const int tid = threadIdx.x, o0 = blockIdx.x * 64;
+    const double* Qg = Qws + (long)k * JP * JP;
+    // Q[s][c] -> (MODE 0) As[s][c]  /  (MODE 1) Bs[s][c]
+    double* Qdst = MODE == 0 ? As : Bs;
+    for (int idx = tid; idx < JP * JP / 2; idx += 256) {
+        const int s = idx >> 5, c = (idx & 31) * 2;
+        *(double2*)(Qdst + s * JLD + c) = *(const double2*)(Qg + s * JP + c);
+    }
+    if (MODE == 0) {
+        // Bs[s][b] = X[row(s)][o0 + b]
+        for (int idx = tid; idx < JP * JP / 2; idx += 256) {
+            const int s = idx >> 5, b = (idx & 31) * 2;
+            *(double2*)(Bs + s * JLD + b) = *(const double2*)(X + (long)jac_row(I, J, s) * ld + o0 + b);
+        }
+    } else {
+        // As[s][a] = X[o0 + a][col(s)]   (transposed while staging)
+        for (int idx = tid; idx < JP * JP / 2; idx += 256) {
+            const int a = idx >> 5, s = (idx & 31) * 2;
+            const double2 v = *(const double2*)(X + (long)(o0 + a) * ld + jac_row(I, J, s));
+            As[s * JLD + a] = v.x;
+            As[(s + 1) * JLD + a] = v.y;
+        }
+    }
+    __syncthreads();
+    const int ta = tid >> 4, tb = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.;
+#pragma unroll 8
+    for (int s = 0; s < JP; ++s) {
+        const double2 a0 = *(const double2*)(As + s * JLD + 4 * ta), a1 = *(const double2*)(As + s * JLD + 4 * ta + 2);
+        const double2 b0 = *(const double2*)(Bs + s * JLD + 4 * tb), b1 = *(const double2*)(Bs + s * JLD + 4 * tb + 2);
+        const double a[4] = {a0.x, a0.y, a1.x, a1.y}, b[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double* dst = X + (long)jac_row(I, J, 4 * ta + i) * ld + o0 + 4 * tb;
+            *(double2*)dst = make_double2(acc[i][0], acc[i][1]);
+            *(double2*)(dst + 2) = make_double2(acc[i][2], acc[i][3]);
+        }
+    } else {
+        // 4 tb .. 4 tb + 3 never straddles the two column blocks (32 is a multiple of 4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double* dst = X + (long)(o0 + 4 * ta + i) * ld + jac_row(I, J, 4 * tb);
+            *(double2*)dst = make_double2(acc[i][0], acc[i][1]);
+            *(double2*)(dst + 2) = make_double2(acc[i][2], acc[i][3]);
+        }
+    }
+}
+
+// lambda_p = K[p][p]; w_p = 1 / lambda_p when |lambda_p| > thresh else 0; VD[:, p] = V[:, p] w_p.
+// res[0] = logdet = sum over kept of log |lambda_p|, res[1] = number of dropped modes among p < n
+// (padding modes are exact 1s: kept, log 1 = 0).  One workgroup computes the scalars (block 0), all scale.
+__global__ __launch_bounds__(256) void k_jac_finish(const double* __restrict__ K, const double* __restrict__ V,
+                                                    double* __restrict__ VD, long ld, int Np, int n, double thresh,
+                                                    double* __restrict__ lam_out, double* __restrict__ res) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ double red[2][4];
+        double lg = 0., nd = 0.;
+        for (int p = tid; p < Np; p += 256) {
+            const double l = K[(long)p * ld + p];
+            lam_out[p] = l;
+            if (fabs(l) > thresh) lg += log(fabs(l));
+            else if (p < n) nd += 1.;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lg += __shfl_down(lg, off); nd += __shfl_down(nd, off); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = lg; red[1][tid >> 6] = nd; }
+        __syncthreads();
+        if (tid == 0) {
+            res[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            res[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        }
+    }
+    const long tot = (long)Np * Np / 2;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < tot; idx += (long)gridDim.x * 256) {
+        const long r = idx / (Np / 2), c = (idx - r * (Np / 2)) * 2;
+        const double l0 = K[c * ld + c], l1 = K[(c + 1) * ld + c + 1];
+        const double2 v = *(const double2*)(V + r * ld + c);
+        *(double2*)(VD + r * ld + c) = make_double2(fabs(l0) > thresh ? v.x / l0 : 0., fabs(l1) > thresh ? v.y / l1 : 0.);
+    }
+}
+
+// upper triangle := mirror of the lower one (in place)
+__global__ void k_mirror_lower(double* __restrict__ M, long ld, int Np) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)Np * Np;
+    for (; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / Np, c = idx - r * Np;
+        if (c > r) M[r * ld + c] = M[c * ld + r];
+    }
+}
+
+// Finish of the pseudo-inverse route.  tall = [H (m rows); zeros; r (row zrow)], T = tall K^+ (same shape):
+// block t < m:  mu_t = H_t . alpha + mean_t  (alpha = row zrow of T),  var_t = (amp_train + kss_noise) - T_t . H_t
+// block m:      loglik = -1/2 r . alpha - n/2 log(2 pi) - 1/2 logdet   (Gaussian_process.py:68-73)
+__global__ __launch_bounds__(256) void k_finish_pinv(
+    const double* __restrict__ tall, const double* __restrict__ T, long ld, int Np, int zrow, int m,
+    const double* __restrict__ mean_new, const KParams* __restrict__ kpp, const double* __restrict__ res,
+    const int* __restrict__ ns, double* __restrict__ mu, double* __restrict__ var, double* __restrict__ scal) {
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* alpha = T + (long)zrow * ld;
+    __shared__ double red[2][4];
+    double s1 = 0., s2 = 0.;
+    if (t < m) {
+        const double* hrow = tall + (long)t * ld;
+        const double* trow = T + (long)t * ld;
+        for (int c = tid * 2; c < Np; c += 512) {
+            const double2 hv = *(const double2*)(hrow + c), av = *(const double2*)(alpha + c), tv = *(const double2*)(trow + c);
+            s1 += hv.x * av.x + hv.y * av.y;
+            s2 += hv.x * tv.x + hv.y * tv.y;
+        }
+    } else {
+        const double* r = tall + (long)zrow * ld;
+        for (int c = tid * 2; c < Np; c += 512) {
+            const double2 rv = *(const double2*)(r + c), av = *(const double2*)(alpha + c);
+            s1 += rv.x * av.x + rv.y * av.y;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+    }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (t < m) {
+            mu[t] = s1 + (mean_new ? mean_new[t] : 0.);
+            var[t] = (kpp->amp_train + kpp->kss_noise) - s2;
+        } else {
+            const double n = (double)ns[0];
+            scal[0] = -0.5 * s1 - 0.5 * n * 1.8378770664093453 - 0.5 * res[0];
+            scal[1] = res[0];
+        }
+    }
+}

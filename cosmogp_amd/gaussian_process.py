@@ -11,10 +11,12 @@ is where the O(N^2)/O(N^3) work happens:
                     O(M) vectors.  N x N matrices never cross PCIe unless a caller reads
                     .kernel_matrix / .inv_kernel_matrix / .covariance_matrix, which are
                     lazy lists filled from the device on first access.
-  svd_method=True   the reference's default algorithm (SVD pseudo-inverse,
-                    inv_matrix.py:4-18), kept for its semantics on singular K.  K and H
-                    are assembled on the GPU, the SVD is SciPy on the host exactly like
-                    the reference (not a GPU target this round).
+  svd_method=True   the reference's default algorithm (pseudo-inverse from the SVD of K with
+                    modes <= 1e-15 dropped, inv_matrix.py:4-18), kept for its semantics on
+                    singular K.  Also ONE device call per object (cgp_fit_svd): K is symmetric, so
+                    its SVD is its eigen-decomposition, computed in HBM by a block Jacobi
+                    eigensolver (csrc/jacobi.hpp); K^+, H K^+ r and K** - H K^+ H' follow with
+                    the MFMA GEMM.  O(20 N^3): use svd_method=False when K is positive definite.
 
 Documented deviations from the reference (SURVEY.md 8a "quirks"):
   * get_prediction with new_binning=None uses each object's own grid; the reference
@@ -29,7 +31,7 @@ from scipy.optimize import fmin
 
 from . import _lib
 from . import kernel as _kernel
-from .inv_matrix import svd_inverse
+from .inv_matrix import svd_inverse, SVD_THRESHOLD
 from .mean import return_mean
 
 REFERENCE_STALE_INDEX = False
@@ -39,11 +41,12 @@ REFERENCE_STALE_INDEX = False
 #: chain of one fit runs in the gaps of the others.  1 = strictly one after the other.
 FITS_IN_FLIGHT = 4
 
-#: Opt-in (SURVEY.md 7 "hard parts"): when True, calls made with the reference's default
-#: svd_method=True first try the GPU Cholesky path, which equals the SVD pseudo-inverse to ~1e-13
-#: whenever K is positive definite (no singular value <= 1e-15 is dropped), and only fall back to the
-#: host SVD when the factorisation reports a non-positive pivot.  False (default) keeps the reference
-#: semantics exactly: svd_method=True always means the SVD algorithm.
+#: svd_method=True (the reference's default) runs the reference's algorithm -- pseudo-inverse from the
+#: decomposition of K with modes <= 1e-15 dropped -- on the device eigensolver (cgp_fit_svd).  Opt-in
+#: shortcut: when True, such calls first try the much faster device Cholesky route, which gives the same
+#: numbers to ~cond(K) eps whenever K is positive definite (no mode is dropped then), and use the
+#: eigensolver only when the factorisation reports a non-positive pivot.  False (default) keeps the
+#: reference semantics exactly: svd_method=True always means the decomposition route.
 SVD_VIA_CHOLESKY_WHEN_PD = False
 
 #: objects per batched launch sequence are capped so that B * (Np + 128) * Np * 8 bytes
@@ -93,15 +96,13 @@ def log_likelihood_gp(y, x_axis, kernel, hyperparameter, nugget, y_err=None, y_m
     y = np.asarray(y, dtype=np.float64)
     resid = y - y_mean
     n = len(x_axis)
-    if svd_method:
-        kern = _kernel.rbf_kernel_1d if dim == 1 else _kernel.rbf_kernel_2d
-        kmat = kern(x_axis, hyperparameter, nugget=nugget, y_err=y_err, device=device)
-        inv, logdet = svd_inverse(kmat, return_logdet=True)
-        ll = -0.5 * np.dot(resid, np.dot(inv, resid.reshape(n, 1)))
-        ll += -(n / 2.) * np.log((2 * np.pi))
-        ll -= 0.5 * logdet
-        return ll
     dev = device if device is not None else _lib.default_device()
+    if svd_method:
+        # reference default: pseudo-inverse route (Gaussian_process.py:54-57), all on the device
+        dev.set_data(dim, x_axis, np.ones(n) * resid)
+        ll = dev.fit_svd(_kparams(dim, hyperparameter, nugget), _kernel.diag_term(n, y_err, 0., 0.),
+                         thresh=SVD_THRESHOLD)[0]
+        return np.array([ll])
     dev.set_data(dim, x_axis, np.ones(n) * resid)
     ll, _, _, _ = dev.fit(_kparams(dim, hyperparameter, nugget), _kernel.diag_term(n, y_err, 0., 0.))
     return np.array([ll])
@@ -219,6 +220,17 @@ class Gaussian_process(object):
             return
         self._fit_single(sn, kp, nugget)
 
+    def _fit_single_svd(self, sn, kp, grid=None, new_y0=None, kss_noise=0., want_cov=False):
+        """One cgp_fit_svd (the reference's default svd_method=True algorithm) for object sn."""
+        dev = self.device
+        diag = None
+        if self._resident != (dev.generation, sn):
+            dev.set_data(self._dim, self.Time[sn], self._resid(sn))
+            self._resident = (dev.generation, sn)
+            diag = self._diag(sn)
+        self._factor_token = None              # the handle's Cholesky factor does not survive this call
+        return dev.fit_svd(kp, diag, grid, new_y0, kss_noise, SVD_THRESHOLD, want_cov)
+
     # ------------------------------------------------------------------ likelihood
     def compute_log_likelihood(self, Hyperparameter, svd_method=True):
         """Summed log marginal likelihood of all objects for one hyperparameter set
@@ -236,9 +248,8 @@ class Gaussian_process(object):
             except np.linalg.LinAlgError:
                 pass
         if svd_method:
-            per_obj = [log_likelihood_gp(self.y[sn], self.Time[sn], self.kernel, hyperparameter, Nugget,
-                                         y_err=self.y_err[sn], y_mean=self.y0[sn], svd_method=True,
-                                         device=self.device)[0] for sn in objs]
+            kp = _kparams(self._dim, hyperparameter, Nugget)
+            per_obj = [self._fit_single_svd(sn, kp)[0] for sn in objs]
         else:
             per_obj = self._loglik_chol(objs, hyperparameter, Nugget)
         if self.comm is not None:
@@ -496,24 +507,34 @@ class Gaussian_process(object):
         self.covariance_matrix = _LazyList(self.N_sn, make)
 
     def _predict_svd(self, hyp, nugget, COV):
-        """Reference default (svd_method=True): SVD pseudo-inverse on the host, K / H from the GPU."""
-        self.inv_kernel_matrix = []
-        self.covariance_matrix = []
+        """Reference default (svd_method=True): pseudo-inverse route, one device call per object
+        (cgp_fit_svd: K, its eigen-decomposition, K^+, H K^+ r and K** - H K^+ H' stay in HBM)."""
+        kp = _kparams(self._dim, hyp, nugget)
+        kss_noise = float(nugget) ** 2
+        hyp = np.array(hyp, dtype=np.float64)
+        covs = [None] * self.N_sn
         for sn in range(self.N_sn):
             new_y0 = self._new_y0(sn)
             self.warning_pf = new_y0
-            inv = svd_inverse(self.kernel_matrix[sn])
-            self.inv_kernel_matrix.append(inv)
-            H = self.kernel(self.Time[sn], hyp, new_x=self._grid(sn), device=self.device)
-            resid = self._resid(sn).reshape(len(self.y[sn]), 1)
-            self.Prediction[sn] = np.dot(H, np.dot(inv, resid)).T[0] + new_y0
+            grid = self._grid(sn)
+            cgrid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
+            same = grid is cgrid or np.array_equal(grid, cgrid)
+            _, _, _, mu, var, cov = self._fit_single_svd(sn, kp, grid, new_y0, kss_noise, want_cov=COV and same)
+            self.Prediction[sn] = mu
+            if COV and not same:
+                # REFERENCE_STALE_INDEX: the mean uses the stale grid, the covariance the object's own (:351-354)
+                _, _, _, _, var, cov = self._fit_single_svd(sn, kp, cgrid, None, kss_noise, want_cov=True)
             if COV:
-                grid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
-                Hc = self.kernel(self.Time[sn], hyp, new_x=grid, device=self.device)
-                Kss = self.kernel(grid, hyp, nugget=nugget, device=self.device)
-                cov = -np.dot(Hc, np.dot(inv, Hc.T)) + Kss
-                self.covariance_matrix.append(cov)
-                self.variance[sn] = np.diag(cov).copy()
+                covs[sn] = cov
+                self.variance[sn] = var
+        if COV:
+            self.covariance_matrix = covs
+
+        def make_inv(sn):
+            return svd_inverse(self.kernel(self.Time[sn], hyp, nugget=nugget, y_err=self.y_err[sn], device=self.device),
+                               device=self.device)
+
+        self.inv_kernel_matrix = _LazyList(self.N_sn, make_inv)
 
 
 class gaussian_process(Gaussian_process):

@@ -1,9 +1,11 @@
 """Mirror of cosmogp/inv_matrix.py: the two callables of the reference's `chol` / `svd` seam
 (cosmogp/Gaussian_process.py:6-9)."""
 import numpy as np
-from scipy import linalg
 
 from . import _lib
+
+#: singular values at or below this are dropped (cosmogp/inv_matrix.py:7)
+SVD_THRESHOLD = 10 ** -15
 
 
 def cholesky_inverse(matrix, return_logdet=False, device=None):
@@ -18,16 +20,19 @@ def cholesky_inverse(matrix, return_logdet=False, device=None):
     return inv
 
 
-def svd_inverse(matrix, return_logdet=False):
-    """SVD pseudo-inverse, singular values <= 1e-15 dropped (cosmogp/inv_matrix.py:4-18).
+def svd_inverse(matrix, return_logdet=False, device=None):
+    """Pseudo-inverse with the singular values <= 1e-15 dropped, on the GPU -- same contract as
+    cosmogp/inv_matrix.py:4-18 (never raises on singular input; logdet = sum of log of the kept
+    singular values; the reference's progress print is dropped).
 
-    HOST code on purpose: this is row a5 of SURVEY.md 8 -- a different algorithm the caller
-    selects with svd_method=True, not part of the accelerated Cholesky path and never used as
-    a substitute for it (8(f) rank 3 lists a device eigensolver as later work).  Like the
-    reference it is SciPy's LAPACK dgesdd; the reference's progress print is dropped."""
-    u, s, vt = linalg.svd(matrix)
-    keep = s > 10 ** -15
-    inv = np.dot(vt.T[:, keep], np.dot(np.diag(1. / s[keep]), u.T[keep]))
+    The matrices of this path are symmetric, so the SVD is the eigen-decomposition
+    (s = |lambda|, U = V sign(lambda)): the device runs a two-sided block Jacobi eigensolver
+    (csrc/jacobi.hpp) and forms V diag(1/lambda) V' with the MFMA GEMM.  For positive definite K the
+    result equals the reference's dgesdd route to ~cond(K) eps; for numerically singular K the modes at
+    the rounding-noise level differ between any two SVD implementations, and so does which of them pass
+    the 1e-15 test."""
+    dev = device if device is not None else _lib.default_device()
+    inv, logdet, _ = dev.svd_inverse(np.asarray(matrix, dtype=np.float64), SVD_THRESHOLD)
     if return_logdet:
-        return inv, np.sum(np.log(s[keep]))
+        return inv, logdet
     return inv

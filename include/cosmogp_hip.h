@@ -88,6 +88,14 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n,
 int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
                          double* inv_out, double* logdet_out);
 
+/* svd(matrix, return_logdet=True) -- cosmogp/inv_matrix.py:4-18: pseudo-inverse of a SYMMETRIC matrix
+ * with the modes whose singular value is <= thresh (reference: 1e-15) dropped; logdet = sum of the logs
+ * of the kept singular values; never fails on singular input.  On the device the SVD of the symmetric K
+ * is its eigen-decomposition (two-sided block Jacobi, csrc/jacobi.hpp): s = |lambda|.
+ * K: (n, n) row stride ldk, both triangles read.  inv_out: (n, n) dense.  n_dropped may be NULL. */
+int cgp_svd_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, double thresh,
+                    double* inv_out, double* logdet_out, int64_t* n_dropped);
+
 /* ---- fused level: one object's fit, matrices stay in HBM ---------------------------- */
 
 /* Upload one object: coordinates x (n or n x 2) and residual r = y - y0 (n doubles).
@@ -110,6 +118,14 @@ int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resi
 int cgp_fit(cgp_handle* h, const double* kp, const double* diag,
             const double* xnew, int64_t m, const double* mean_new, double kss_noise,
             double* loglik, double* logdet, double* mu, double* var);
+
+/* The same fit by the reference's svd_method=True algorithm (Gaussian_process.py:54-57, :319-320): K is
+ * assembled in HBM, eigen-decomposed there, K^+ replaces K^-1 in the likelihood (:68-73), the prediction
+ * (:334-335) and the predictive covariance (:356-361).  cov: NULL or (m, m) dense.  Invalidates the
+ * Cholesky factor of the handle.  Returns 0 also for singular K (modes <= thresh are dropped). */
+int cgp_fit_svd(cgp_handle* h, const double* kp, const double* diag,
+                const double* xnew, int64_t m, const double* mean_new, double kss_noise, double thresh,
+                double* loglik, double* logdet, int64_t* n_dropped, double* mu, double* var, double* cov);
 
 /* Prediction on further points with the factor left by the last cgp_fit (same kp).
  * cov: NULL or (m, m) dense = K(new,new; nugget) - H K^-1 H'  [Gaussian_process.py:356-361] */

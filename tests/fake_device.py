@@ -67,6 +67,29 @@ class FakeDevice(object):
         ll, mu, var = self._one(self.dim, self.x, self.r, self.diag, kp, xnew, mean_new, kss_noise)
         return ll, 0., mu, var
 
+    def svd_inverse(self, K, thresh=1e-15):
+        inv, logdet = orc.svd_inverse(np.asarray(K, float), return_logdet=True)
+        return inv, logdet, 0
+
+    def fit_svd(self, kp, diag=None, xnew=None, mean_new=None, kss_noise=0., thresh=1e-15, want_cov=False):
+        self.calls.append('fit_svd')
+        if diag is not None:
+            self.diag = np.array(diag)
+        self.kp = np.array(kp)
+        kern = _kernel_from_kp(self.dim, kp)
+        K = kern(self.x, None, self.diag)
+        inv, logdet = orc.svd_inverse(K, return_logdet=True)
+        n = len(self.r)
+        ll = -0.5 * self.r @ inv @ self.r - 0.5 * n * np.log(2 * np.pi) - 0.5 * logdet
+        if xnew is None:
+            return ll, logdet, 0, None, None, None
+        H = kern(self.x, xnew)
+        mu = H @ inv @ self.r + (0. if mean_new is None else mean_new)
+        kp0 = self.kp.copy()
+        kp0[6] = 0.
+        cov = _kernel_from_kp(self.dim, kp0)(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ inv @ H.T
+        return ll, logdet, 0, mu, np.diag(cov).copy(), cov if want_cov else None
+
     def fit_grad(self, kp, diag=None):
         """Moment sums of include/cosmogp_hip.h (cgp_fit_grad), from dense NumPy."""
         self.calls.append('fit_grad')

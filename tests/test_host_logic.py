@@ -81,15 +81,6 @@ def test_return_mean_vs_oracle():
             fn(Y, X, mean_y=YM, mean_xaxis=XM)
 
 
-def test_svd_inverse_golden():
-    g = load_golden('inverse_n96')
-    inv, ld = cosmogp_amd.svd_inverse(g['K'], return_logdet=True)
-    np.testing.assert_allclose(inv, g['svd_inv'], rtol=0, atol=1e-11 * np.abs(g['svd_inv']).max())
-    assert abs(ld - float(g['svd_logdet'])) <= 1e-12 * abs(ld)
-    inv, ld = cosmogp_amd.svd_inverse(g['K_singular'], return_logdet=True)       # never raises
-    assert abs(ld - float(g['svd_logdet_singular'])) <= 1e-9 * abs(ld)
-
-
 def test_lazy_list():
     calls = []
 
