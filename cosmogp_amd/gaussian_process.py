@@ -41,13 +41,17 @@ REFERENCE_STALE_INDEX = False
 #: chain of one fit runs in the gaps of the others.  1 = strictly one after the other.
 FITS_IN_FLIGHT = 4
 
-#: svd_method=True (the reference's default) runs the reference's algorithm -- pseudo-inverse from the
-#: decomposition of K with modes <= 1e-15 dropped -- on the device eigensolver (cgp_fit_svd).  Opt-in
-#: shortcut: when True, such calls first try the much faster device Cholesky route, which gives the same
-#: numbers to ~cond(K) eps whenever K is positive definite (no mode is dropped then), and use the
-#: eigensolver only when the factorisation reports a non-positive pivot.  False (default) keeps the
-#: reference semantics exactly: svd_method=True always means the decomposition route.
-SVD_VIA_CHOLESKY_WHEN_PD = False
+#: svd_method=True (the reference's default) means: pseudo-inverse from the decomposition of K with the
+#: modes whose singular value is <= 1e-15 dropped (inv_matrix.py:4-18).  How it is computed:
+#:   False   always by the device eigensolver (cgp_fit_svd), the reference's algorithm literally;
+#:   'auto'  (default) K = K_rbf + diag(y_err^2 + nugget^2) with K_rbf positive semi-definite, so every
+#:           eigenvalue of K is >= min(y_err^2) + nugget^2: when that bound exceeds 1e-14 NO mode can be
+#:           dropped, the pseudo-inverse IS the inverse, and the call is served by the device Cholesky
+#:           route (same numbers to ~cond(K) eps, ~1000x faster); otherwise, or when the factorisation
+#:           meets a non-positive pivot, by the eigensolver;
+#:   True    try the Cholesky route first whatever the bound says, eigensolver on a non-positive pivot.
+SVD_VIA_CHOLESKY_WHEN_PD = 'auto'
+
 
 #: objects per batched launch sequence are capped so that B * (Np + 128) * Np * 8 bytes
 #: stays below this (HBM is 288 GB; leave room for several handles)
@@ -178,6 +182,13 @@ class Gaussian_process(object):
         """y_err**2 + floor**2 (floor = 0); the nugget**2 term travels in kp[6]."""
         return _kernel.diag_term(len(self.y[sn]), self.y_err[sn], 0., 0.)
 
+    def _svd_by_cholesky(self, nugget):
+        """May a svd_method=True call be served by the Cholesky route? (see SVD_VIA_CHOLESKY_WHEN_PD)"""
+        if SVD_VIA_CHOLESKY_WHEN_PD == 'auto':
+            bound = min(float(np.min(self._diag(sn))) if len(self.y[sn]) else np.inf for sn in range(self.N_sn))
+            return bound + float(nugget) ** 2 > 1e-14
+        return bool(SVD_VIA_CHOLESKY_WHEN_PD)
+
     def _my_objects(self):
         if self.comm is None:
             return list(range(self.N_sn))
@@ -242,7 +253,7 @@ class Gaussian_process(object):
             Nugget = self.nugget
             hyperparameter = Hyperparameter
         objs = self._my_objects()
-        if svd_method and SVD_VIA_CHOLESKY_WHEN_PD:
+        if svd_method and self._svd_by_cholesky(Nugget):
             try:
                 return self.compute_log_likelihood(Hyperparameter, svd_method=False)
             except np.linalg.LinAlgError:
@@ -411,7 +422,7 @@ class Gaussian_process(object):
         nugget = self.nugget
         self.Prediction = [None] * self.N_sn
         self.variance = [None] * self.N_sn
-        if svd_method and SVD_VIA_CHOLESKY_WHEN_PD:
+        if svd_method and self._svd_by_cholesky(nugget):
             try:
                 return self.get_prediction(new_binning=new_binning, COV=COV, svd_method=False)
             except np.linalg.LinAlgError:

@@ -14,11 +14,25 @@ from oracle import cosmogp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+import sys
+
+
 @pytest.fixture(scope='module')
 def cg():
     import cosmogp_amd
     cosmogp_amd._lib.default_device()
     return cosmogp_amd
+
+
+@pytest.fixture
+def eigen_route(cg):
+    """svd_method=True literally = the device eigensolver (the default 'auto' would serve these noisy
+    objects by the Cholesky route)."""
+    gpm = sys.modules['cosmogp_amd.gaussian_process']
+    old = gpm.SVD_VIA_CHOLESKY_WHEN_PD
+    gpm.SVD_VIA_CHOLESKY_WHEN_PD = False
+    yield gpm
+    gpm.SVD_VIA_CHOLESKY_WHEN_PD = old
 
 
 def test_svd_inverse_golden_pd(cg):
@@ -77,7 +91,7 @@ def test_svd_inverse_indefinite(cg):
     assert abs(ld - ldr) <= 1e-11 * abs(ldr)
 
 
-def test_fit_svd_vs_oracle_2d(cg):
+def test_fit_svd_vs_oracle_2d(cg, eigen_route):
     rng = np.random.default_rng(8)
     n, m = 300, 70
     x = rng.uniform(0., 30., (n, 2))
@@ -103,7 +117,7 @@ def test_fit_svd_vs_oracle_2d(cg):
     np.testing.assert_allclose(gp.log_likelihood, ll_svd, rtol=1e-11)
 
 
-def test_fit_svd_default_fit_reaches_reference_optimum(cg):
+def test_fit_svd_default_fit_reaches_reference_optimum(cg, eigen_route):
     gg = load_golden('fit_1d_n60')
     gp = cg.gaussian_process(gg['y'], gg['x'], kernel='RBF1D', y_err=gg['e'])
     gp.find_hyperparameters(hyperparameter_guess=list(gg['guess']))          # all defaults, like a reference user
@@ -121,3 +135,31 @@ def test_eigen_n1024_accuracy(cg):
     assert abs(ld - ldr) <= 1e-10 * abs(ldr)
     np.testing.assert_allclose(K @ inv, np.eye(n), rtol=0, atol=1e-9)
     assert cg._lib.default_device() is not None
+
+
+def test_auto_route_selection(cg):
+    """Default 'auto': noisy objects (no mode can be dropped) are served by the Cholesky route, noise-free
+    ones by the eigensolver; both without the caller changing svd_method."""
+    rng = np.random.default_rng(4)
+    n = 150
+    x = np.sort(rng.uniform(0., 20., n))
+    y = np.sin(x / 2.)
+    calls = []
+    dev = cg._lib.Device()
+    real = dev.fit_svd
+    dev.fit_svd = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    gp = cg.gaussian_process(y, x, kernel='RBF1D', y_err=np.full(n, 0.1), device=dev)
+    gp.hyperparameters = [1., 2.]
+    gp.get_prediction(new_binning=np.linspace(0., 20., 40))          # svd_method=True by default
+    gp.compute_log_likelihood([1., 2.])
+    assert calls == []
+    want = orc.predict([y], [x], 'RBF1D', [1., 2.], 0., [np.full(n, 0.1)], new_binning=np.linspace(0., 20., 40),
+                       svd_method=True)
+    np.testing.assert_allclose(gp.Prediction[0], want['prediction'][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gp.covariance_matrix[0], want['covariance'][0], rtol=0, atol=1e-9)
+    g0 = cg.gaussian_process(y, x, kernel='RBF1D', device=dev)        # y_err = None: K is numerically singular
+    g0.hyperparameters = [1., 2.]
+    g0.get_prediction(new_binning=np.linspace(0., 20., 40))
+    assert len(calls) == 1 and np.all(np.isfinite(g0.Prediction[0]))
+    with pytest.raises(np.linalg.LinAlgError):
+        g0.get_prediction(new_binning=np.linspace(0., 20., 40), svd_method=False)

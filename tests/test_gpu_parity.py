@@ -543,7 +543,7 @@ def test_graph_replay_with_new_hyperparameters(cg):
 
 def test_svd_method_optin_routes_to_cholesky_when_pd(cg):
     """Opt-in: svd_method=True (the reference default) tries the GPU Cholesky first; on PD input it agrees
-    with the golden SVD answers, on singular input it falls back to the host SVD like the reference."""
+    with the golden SVD answers, on singular input the device eigensolver takes over (never raises, like the reference)."""
     import sys
     gpm = sys.modules['cosmogp_amd.gaussian_process']
     g = load_golden('c1_predict_1d_n256')
@@ -562,7 +562,7 @@ def test_svd_method_optin_routes_to_cholesky_when_pd(cg):
         gs.get_prediction(new_binning=x[:5], svd_method=True)        # falls back, never raises
         assert np.all(np.isfinite(gs.Prediction[0]))
     finally:
-        gpm.SVD_VIA_CHOLESKY_WHEN_PD = False
+        gpm.SVD_VIA_CHOLESKY_WHEN_PD = 'auto'
 
 
 def test_nobject_fit_with_resident_batch(cg):
