@@ -204,7 +204,9 @@ int leaf_attr_once(cgp_handle* h) {
     bool& done = done_dev[h->device & 63];
     if (done) return 0;
     HIPCHK(hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
     done = true;
     return 0;
 }
@@ -338,8 +340,22 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
         const long Re = P.rend(R, c0 + NB);
         if (Re > r0) {
             StageScope sc(h, ST_TRSM);
-            hipLaunchKernelGGL(k_trsm_panel, dim3((unsigned)((Re - r0) / (16 * CGP_K4_WAVES)), 1, P.B), dim3(64 * CGP_K4_WAVES), LEAF_LDS, S,
-                               P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+            // 16 rows per wave; one workgroup holds L_kk in LDS and is alone on its CU, so use the fewest
+            // waves per workgroup that still puts the whole launch on the chip at once (a single fit: 4 waves,
+            // 1 per SIMD, shortest chain; a batch of small problems: up to 16, rows of 256)
+            const long rows = Re - r0, cus = 256;
+            const int force = getenv("CGP_K4_WAVES") ? atoi(getenv("CGP_K4_WAVES")) : 0;
+            int w = 4;
+            if (force) w = force;
+            else if ((rows / 64) * P.B > cus) w = ((rows / 128) * P.B > cus && rows % 256 == 0) ? 16 : 8;
+            if (rows % (16 * w) != 0) w = 4;
+            const dim3 g((unsigned)(rows / (16 * w)), 1, P.B);
+            if (w == 4)
+                hipLaunchKernelGGL(k_trsm_panel<4>, g, dim3(256), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+            else if (w == 8)
+                hipLaunchKernelGGL(k_trsm_panel<8>, g, dim3(512), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+            else
+                hipLaunchKernelGGL(k_trsm_panel<16>, g, dim3(1024), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
             HIPCHK(hipGetLastError());
         }
         return 0;                                // leaf kernels run on the main stream in order: no mark needed

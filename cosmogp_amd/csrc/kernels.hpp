@@ -468,11 +468,9 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
 // layout; a finished X_j goes through a wave-private LDS tile to be re-read as an A operand.
 // L_kk (strictly lower 16x16 tiles) and the T_j^-T blocks are staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------
-#ifndef CGP_K4_WAVES
-#define CGP_K4_WAVES 4   // waves (16 panel rows each) per workgroup
-#endif
 
-__global__ __launch_bounds__(64 * CGP_K4_WAVES) void k_trsm_panel(
+template <int K4W>
+__global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
     long sW, int blk) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -485,9 +483,10 @@ __global__ __launch_bounds__(64 * CGP_K4_WAVES) void k_trsm_panel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
     // wave-private 16 x 16 tile, kept in the part of Ls that is never loaded (tiles on/above the diagonal):
-    // rows 16 g .. 16 g + 15 (g = wave / 4), columns 16 + 18 (wave % 4) ..; row stride CGP_LDA
-    double* Xs = Ls + (wave >> 2) * 16 * CGP_LDA + 16 + 18 * (wave & 3);
-    double* Ap = M + (long)(r0 + blockIdx.x * (16 * CGP_K4_WAVES) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
+    // tile rows g = 0, 1 offer columns 16..127 (6 slots of 18), g = 2 columns 32..127 (5 slots); row stride CGP_LDA
+    const int xg = wave < 6 ? 0 : (wave < 12 ? 1 : 2), xt = wave - 6 * xg;
+    double* Xs = Ls + xg * 16 * CGP_LDA + (xg == 2 ? 32 : 16) + 18 * xt;
+    double* Ap = M + (long)(r0 + blockIdx.x * (16 * K4W) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
 
     CGP_STAMP(50);
     // This wave's 16 x 128 panel rows in MFMA result layout.  The column slot (J, u) of a 16-wide
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(64 * CGP_K4_WAVES) void k_trsm_panel(
         S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
     }
     // L_kk strictly-lower tiles -> LDS (all loads of a batch in flight before the LDS writes)
-    constexpr int K4T = 64 * CGP_K4_WAVES;
+    constexpr int K4T = 64 * K4W;
 #pragma unroll
     for (int batch = 0; batch < 1024 / K4T; ++batch) {
         d2 tmp[8];

@@ -16,12 +16,12 @@ int main() {
     hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     size_t lds = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144) * 8;
     hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)k_trsm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_trsm_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     unsigned long long st[256];
     for (int rep = 0; rep < 2; ++rep) {
         hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(CGP_K3_THREADS), lds, 0, M, ld, 0L, 0, ws, 0L, ldp, 0L, info, 0);
-        hipLaunchKernelGGL(k_trsm_panel, dim3((R - 128) / 64), dim3(256), lds, 0, M, ld, 0L, 0, 128, ws, 0L, 0);
+        hipLaunchKernelGGL(k_trsm_panel<4>, dim3((R - 128) / 64), dim3(256), lds, 0, M, ld, 0L, 0, 128, ws, 0L, 0);
         hipDeviceSynchronize();
     }
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
