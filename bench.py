@@ -292,7 +292,7 @@ def main():
             roof['by_form'] = {
                 'k_gemm_nt<128,64,4,2,16>': dict(launches_per_fit=int(st[9]), avg_launch_ms=round(st[8] / st[9], 5),
                                                  achieved=round(st[10] / (st[8] * 1e-3) / 1e12, 3)),
-                'k_gemm_nt<64,64,1,4,16>': dict(launches_per_fit=int(launches - st[9]),
+                'k_gemm_nt<64,64,2,4,16>': dict(launches_per_fit=int(launches - st[9]),
                                                 avg_launch_ms=round((gemm_ms - st[8]) / max(1., launches - st[9]), 5),
                                                 achieved=round((flops - st[10]) / ((gemm_ms - st[8]) * 1e-3) / 1e12, 3))}
         t_one = time.perf_counter()

@@ -24,7 +24,7 @@ constexpr int NB = CGP_NB;
 #define GEMM_BIG_WN 2
 #endif
 #ifndef GEMM_SMALL_WM
-#define GEMM_SMALL_WM 1
+#define GEMM_SMALL_WM 2
 #define GEMM_SMALL_WN 4
 #endif
 #ifndef GEMM_KB_BIG

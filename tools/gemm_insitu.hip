@@ -102,8 +102,9 @@ int main(int argc, char** argv) {
     run<64, 64, 1, 4, 16>("64x64 4w(64x16)", M, ld, us);
     run<128, 64, 4, 2, 16>("128x64 8w(32x32)", M, ld, us);
     run<128, 64, 2, 4, 16>("128x64 8w(64x16)", M, ld, us);
-    run<128, 64, 2, 4, 16, 1>("128x64 8w(64x16) no-global", M, ld, us);
-    run<128, 64, 2, 4, 16, 2>("128x64 8w(64x16) no-glb/lds", M, ld, us);
-    run<64, 64, 1, 4, 16, 1>("64x64 4w(64x16) no-global", M, ld, us);
+    run<64, 64, 2, 4, 16>("64x64 8w(32x16)", M, ld, us);
+    run<64, 64, 2, 2, 16>("64x64 4w(32x32)", M, ld, us);
+    run<64, 32, 2, 2, 16>("64x32 4w(32x16)", M, ld, us);
+    run<64, 32, 1, 2, 16>("64x32 2w(64x16)", M, ld, us);
     return 0;
 }
