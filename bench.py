@@ -152,6 +152,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='only the checked fit and the timed steps (for rocprofv3 --pmc passes: every fit in the '
+                         'process is then a full fit of the workload); the JSON line has no roofline / extras')
     ap.add_argument('--streams', type=int, default=0,
                     help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
                          'buffers); 1 = strictly one fit at a time; 0 = auto: 4 for single-fit / sweep '
@@ -229,7 +232,11 @@ def main():
 
     all_devs = [dev] + extra_devs
 
-    def run_on(d, k, offset):
+    stagger_s = float(os.environ.get('CGP_BENCH_STAGGER_MS', '0')) * 1e-3
+
+    def run_on(d, k, offset, slot=0):
+        if stagger_s > 0. and slot > 0:
+            time.sleep(stagger_s * slot)
         # k device-resident fits (or batches of fits) back to back on this handle's stream, then sync:
         # the last cgp_fit / cgp_batch_fit left every input in HBM
         if 'sweep' in wl:
@@ -246,8 +253,8 @@ def main():
         if len(all_devs) == 1:
             return run_on(dev, share[0], 0)
         ths, off = [], 0
-        for d, n_ in zip(all_devs, share):
-            ths.append(threading.Thread(target=run_on, args=(d, n_, off)))
+        for slot, (d, n_) in enumerate(zip(all_devs, share)):
+            ths.append(threading.Thread(target=run_on, args=(d, n_, off, slot)))
             off += n_
         for t in ths:
             t.start()
@@ -273,7 +280,7 @@ def main():
 
     # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
     roof, extra = None, {}
-    if not batched:
+    if not batched and not args.no_extras:
         ms_fit, st = dev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
