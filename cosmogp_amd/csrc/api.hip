@@ -218,6 +218,11 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
                 hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
+    if (bulk_cap == 0 && B == 1 && tile_skip == 0 && !ktri && getenv("CGP_BULK_CAP") && rows % 128 == 0 && cols % 128 == 0) {
+        // experiment: large updates as persistent 128 x 128 tiles on at most CGP_BULK_CAP workgroups
+        const long nt_ = cols / 128, tl = tri ? nt_ * (nt_ + 1) / 2 + (rows / 128 - nt_) * nt_ : (rows / 128) * nt_;
+        if (tl >= 512) bulk_cap = atoi(getenv("CGP_BULK_CAP"));
+    }
     const long nt128_ = cols / 128;
     const long tiles_big_ = (tri ? nt128_ * (nt128_ + 1) + (rows / 128 - nt128_) * (cols / 64) : (rows / 128) * (cols / 64));
     const bool big_form = bulk_cap == 0 &&
