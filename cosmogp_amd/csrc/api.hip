@@ -254,9 +254,21 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         // tile_skip counts 64 x 64 tiles of the leading 128 x 128 diagonal block (3); in this tiling that
         // block is the first 2 tiles
         const int skip = tile_skip ? 2 : 0;
+        // CGP_GEMM_CHUNK=n: issue the update in launches of n tiles (one round of the chip each), so that the
+        // leaf kernels of other fits in flight find free CUs at every chunk boundary
+        static const long chunk = getenv("CGP_GEMM_CHUNK") ? atol(getenv("CGP_GEMM_CHUNK")) : 0;
+        if (chunk > 0 && B == 1 && tiles_big - skip > chunk + chunk / 2) {
+            for (long t0 = skip; t0 < tiles_big; t0 += chunk) {
+                const long t1 = std::min(t0 + chunk, tiles_big);
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, GEMM_BIG_WM, GEMM_BIG_WN, GEMM_KB_BIG>), dim3((unsigned)(t1 - t0), 1, 1),
+                                   dim3(64 * GEMM_BIG_WM * GEMM_BIG_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB, (int)K,
+                                   (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, (int)t0, ktri ? 1 : 0, (int)t1);
+            }
+        } else {
         dim3 g((unsigned)(tiles_big - skip), 1, (unsigned)B);
         hipLaunchKernelGGL((k_gemm_nt<128, 64, GEMM_BIG_WM, GEMM_BIG_WN, GEMM_KB_BIG>), g, dim3(64 * GEMM_BIG_WM * GEMM_BIG_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)(rows / 128), (int)(cols / 64), tri ? 1 : 0, alpha, beta, skip, ktri ? 1 : 0);
+        }
     } else {
         const long nr = rows / 64, nc = cols / 64;
         const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;

@@ -596,7 +596,8 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
 template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
-    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri) {
+    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
+    int tile_end = 0) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -622,7 +623,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     static_assert(TM == RT * TN && (RT == 1 || RT == 2), "tile shape");
     const int nt = nc / RT;
     const int ntri = tri ? RT * nt * (nt + 1) / 2 : 0;
-    const int ntot = ntri + (nr - (tri ? nt : 0)) * nc;
+    const int ntot_all = ntri + (nr - (tri ? nt : 0)) * nc;
+    const int ntot = tile_end > 0 ? min(tile_end, ntot_all) : ntot_all;     // tile_end: this launch covers tiles [tile_skip, tile_end)
     // Persistent tile loop: a launch with fewer workgroups than tiles walks the tile list with stride
     // gridDim.x (bulk updates are launched with <= 240 workgroups of this 1-per-CU kernel so that some
     // CUs stay free for the latency-critical leaf kernels of the other stream).
