@@ -473,8 +473,11 @@ int cgp_create(int device, cgp_handle** out) {
     if (hipGetDeviceCount(&c) != hipSuccess || device < 0 || device >= c) return CGP_E_HIP;
     cgp_handle* h = new cgp_handle();
     h->device = device;
+    // the second stream exists only for the opt-in look-ahead experiment (it also shifts how the runtime deals
+    // streams onto its hardware queues)
+    const bool want2 = getenv("CGP_LOOKAHEAD") != nullptr || getenv("CGP_STREAM2") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) {
+        (want2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess)) {
         delete h;
         return CGP_E_HIP;
     }
@@ -496,7 +499,7 @@ int cgp_destroy(cgp_handle* h) {
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->fork_events) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(h->stream2);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return CGP_OK;
@@ -633,8 +636,10 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     // capture (a failed capture falls back to eager launches)
     cgp_handle::CachedGraph cg;
     cg.key = key;
+    if (getenv("CGP_LOOKAHEAD") && !h->stream2 &&
+        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) h->stream2 = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->trk.active = getenv("CGP_LOOKAHEAD") != nullptr;      // opt-in: measured slower
+    h->trk.active = getenv("CGP_LOOKAHEAD") != nullptr && h->stream2;      // opt-in: measured slower
     h->fork_used = 0;
     int st = device_fit_eager(h, P, m, has_mean);
     h->trk.active = false;
