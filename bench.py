@@ -35,10 +35,10 @@ SPEC_FP64_MFMA_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (AMD
 SPEC_HBM_GBS = 8000.0
 
 
-def make_workload(name, rank=0):
+def make_workload(name, rank=0, obj=0):
     from cosmogp_amd import kernel as K
     if name == 'c3':
-        rng = np.random.default_rng(3 + 1000 * rank)
+        rng = np.random.default_rng(3 + 1000 * rank + 37 * obj)
         n, m = 8192, 2500
         X = rng.uniform(0., 2048., (n, 2))
         g = np.linspace(20., 2028., 50)
@@ -48,12 +48,13 @@ def make_workload(name, rank=0):
         return dict(dim=2, n=n, m=m, x=X, y=y, e=np.full(n, 0.1), xnew=Xn, hyp=hyp,
                     kp=K.kernel_params_2d(hyp), label='2D RBF GP N=8192 M=2500 single fit (BASELINE config[2])')
     if name == 'c2':
-        rng = np.random.default_rng(2 + 1000 * rank)
+        rng = np.random.default_rng(2 + 1000 * rank + 37 * obj)
         n, m = 4096, 1024
         x = np.sort(rng.uniform(0., 400., n))
         y = np.sin(0.05 * x) + 0.3 * np.cos(0.31 * x) + 0.1 * rng.standard_normal(n)
         hyp = [1., 2.]
-        return dict(dim=1, n=n, m=m, x=x, y=y, e=np.full(n, 0.1), xnew=rng.uniform(0., 400., m), hyp=hyp,
+        return dict(dim=1, n=n, m=m, x=x, y=y, e=np.full(n, 0.1),
+                    xnew=np.random.default_rng(20 + 1000 * rank).uniform(0., 400., m), hyp=hyp,
                     kp=K.kernel_params_1d(hyp), label='1D RBF GP N=4096 M=1024 single fit (BASELINE config[1])')
     if name == 'c4':
         B, n, m = 128, 512, 19
@@ -155,6 +156,12 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='only the checked fit and the timed steps (for rocprofv3 --pmc passes: every fit in the '
                          'process is then a full fit of the workload); the JSON line has no roofline / extras')
+    ap.add_argument('--batch', type=int, default=-1,
+                    help='c2 / c3: independent fits (distinct objects of the configured size) per launch sequence. '
+                         'They go through the batched entry point (cgp_batch_fit, the path gaussian_process_nobject '
+                         'uses): one launch sequence factors all of them in lock-step, which amortises the '
+                         'latency-bound leaf chain. -1 = auto (8); 1 = one object per launch sequence (then '
+                         '--streams handles overlap whole fits instead)')
     ap.add_argument('--streams', type=int, default=0,
                     help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
                          'buffers); 1 = strictly one fit at a time; 0 = auto: 4 for single-fit / sweep '
@@ -182,7 +189,8 @@ def main():
     dev.selftest_mfma()
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
-    nstreams = args.streams if args.streams > 0 else (1 if batched else 4)
+    lock = 1 if (batched or 'sweep' in wl) else (8 if args.batch < 0 else max(1, args.batch))
+    nstreams = args.streams if args.streams > 0 else (1 if batched else (2 if lock > 1 else 4))
     # Independent fits are the unit of this path (objects, candidates): with several in flight the
     # latency-bound leaf chain of one fit runs in the gaps of the others' bulk updates.  Every handle has
     # its own stream and its own copy of the inputs in HBM; each fit is still one full pass.
@@ -215,14 +223,25 @@ def main():
         diag = K.diag_term(wl['n'], wl['e'], 0., 0.)
         ll, ld, mu, var = dev.fit(wl['kp'], diag, wl['xnew'], None, 0.)
         assert np.isfinite(ll) and np.all(np.isfinite(mu)) and var.min() > -1e-9
-        for d in extra_devs:
-            d.set_data(wl['dim'], wl['x'], wl['y'])
-            out = d.fit(wl['kp'], diag, wl['xnew'], None, 0.)
-            assert out[0] == ll and np.array_equal(out[2], mu)          # every handle computes the same fit
+        if lock > 1:
+            # `lock` distinct objects per launch sequence, resident on every handle of the timed region (dev keeps
+            # the single object for the roofline pass); object 0 must come out bit-identical to its single fit
+            objs = [wl] + [make_workload(args.workload, rank, obj=i) for i in range(1, lock)]
+            bdiags = [K.diag_term(o['n'], o['e'], 0., 0.) for o in objs]
+            fit_devs = extra_devs + [_lib.Device(local_rank)]
+            for d in fit_devs:
+                bll, binfo, bmu, bvar = d.batch_fit(wl['dim'], [o['x'] for o in objs], [o['y'] for o in objs], bdiags,
+                                                    wl['kp'], wl['xnew'], None, 0.)
+                assert not binfo.any() and bll[0] == ll and np.array_equal(bmu[0], mu) and np.array_equal(bvar[0], var)
+        else:
+            for d in extra_devs:
+                d.set_data(wl['dim'], wl['x'], wl['y'])
+                out = d.fit(wl['kp'], diag, wl['xnew'], None, 0.)
+                assert out[0] == ll and np.array_equal(out[2], mu)          # every handle computes the same fit
         units_per_step = 1
 
     def sync_all():
-        for d in [dev] + extra_devs:
+        for d in set([dev] + extra_devs + (fit_devs if lock > 1 else [])):
             d._lib.cgp_synchronize(d._h)
         if dist is not None:
             import torch
@@ -230,7 +249,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    all_devs = [dev] + extra_devs
+    all_devs = fit_devs if lock > 1 else [dev] + extra_devs
 
     stagger_s = float(os.environ.get('CGP_BENCH_STAGGER_MS', '0')) * 1e-3
 
@@ -243,6 +262,12 @@ def main():
             # one hyper-parameter set per evaluation: 7 doubles go down, 1 comes back (data resident)
             for i in range(k):
                 d.fit(kps[(offset + i) % len(kps)], None)
+        elif k > 0 and lock > 1:
+            # k fits = k // lock passes over the whole resident batch + one pass over the first k % lock objects
+            if k // lock:
+                d.bench_fit_objects(k // lock, lock)
+            if k % lock:
+                d.bench_fit_objects(1, k % lock)
         elif k > 0:
             d.bench_fit(k, stages=False)
 
@@ -261,6 +286,12 @@ def main():
         for t in ths:
             t.join()
 
+    if lock > 1:
+        # capture the launch graph of the partial pass each handle will need (k % lock objects) outside the timed region
+        for i, d in enumerate(all_devs):
+            k_i = args.steps // len(all_devs) + (1 if i < args.steps % len(all_devs) else 0)
+            if k_i % lock:
+                d.bench_fit_objects(1, k_i % lock)
     run_steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()
@@ -340,8 +371,10 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                     config=dict(workload=wl['label'], n=wl['n'], m=wl['m'], dim=wl['dim'],
-                                fits_per_step_per_gpu=units_per_step, fits_in_flight_per_gpu=nstreams,
-                                parallelism='independent fits, 1 rank per GPU, %d handles (streams) per GPU' % nstreams),
+                                fits_per_step_per_gpu=units_per_step, fits_in_flight_per_gpu=nstreams * lock,
+                                objects_per_launch_sequence=lock, handles_per_gpu=nstreams,
+                                parallelism='independent fits, 1 rank per GPU, %d handles (HIP streams) per GPU, '
+                                            '%d distinct objects per launch sequence' % (nstreams, lock)),
                     roofline=roof)
         if n_gpus == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(wl)

@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
-    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 
@@ -72,6 +72,7 @@ def load_library():
                                       _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
+        lib.cgp_bench_fit_objects.argtypes = [vp, ctypes.c_int, _i64, _dp]
         lib.cgp_microbench.argtypes = [vp, _dp, _dp]
         lib.cgp_selftest_mfma.argtypes = [vp]
         _lib = lib
@@ -312,6 +313,13 @@ class Device(object):
         st8 = np.zeros(12) if stages else None
         self._check(self._lib.cgp_bench_fit(self._h, int(iters), ctypes.byref(ms), _ptr(st8)), 'cgp_bench_fit')
         return ms.value, st8
+
+    def bench_fit_objects(self, iters, nobj):
+        """iters device-resident passes over the first nobj objects of the resident batch; ms per pass."""
+        ms = ctypes.c_double(0.)
+        self._check(self._lib.cgp_bench_fit_objects(self._h, int(iters), int(nobj), ctypes.byref(ms)),
+                    'cgp_bench_fit_objects')
+        return ms.value
 
     def microbench(self):
         a, b = ctypes.c_double(0.), ctypes.c_double(0.)

@@ -1276,6 +1276,33 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
     return CGP_OK;
 }
 
+int cgp_bench_fit_objects(cgp_handle* h, int iters, int64_t nobj, double* ms_per_pass) {
+    CHK(begin_call(h));
+    if (iters <= 0 || !ms_per_pass) return fail(h, CGP_E_ARG, "cgp_bench_fit_objects: bad argument");
+    if (!h->last_was_batch || !h->have_batch) return fail(h, CGP_E_STATE, "cgp_bench_fit_objects: run cgp_batch_fit first");
+    Prob& P = h->Q;
+    if (nobj <= 0 || nobj > P.B) return fail(h, CGP_E_ARG, "cgp_bench_fit_objects: nobj outside the resident batch");
+    const int Bfull = P.B;
+    P.B = (int)nobj;                         // the first nobj objects: same buffers and strides
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    h->profiling = false;
+    int st = 0;
+    HIPCHK(hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters && st >= 0; ++i) st = device_fit(h, P, h->last_m, h->last_has_mean);
+    P.B = Bfull;
+    if (st < 0) return st;
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_pass = (double)ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return CGP_OK;
+}
+
 int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs) {
     CHK(begin_call(h));
     hipEvent_t e0, e1;

@@ -179,6 +179,10 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
  * stage_ms must hold 12 doubles. */
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
 
+/* Same for the resident BATCH (after cgp_batch_fit): `iters` passes over its first nobj objects
+ * (1 <= nobj <= B), all in one launch sequence; ms_per_pass = time of one pass. */
+int cgp_bench_fit_objects(cgp_handle* h, int iters, int64_t nobj, double* ms_per_pass);
+
 /* Bare v_mfma_f64_4x4x4_4b_f64 issue loop on every CU: measured fp64 matrix ceiling (TFLOP/s),
  * and a streaming-store kernel: measured HBM write ceiling (GB/s). */
 int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs);
