@@ -154,8 +154,9 @@ def main():
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
-                    help='only the checked fit and the timed steps (for rocprofv3 --pmc passes: every fit in the '
-                         'process is then a full fit of the workload); the JSON line has no roofline / extras')
+                    help='skip the one-fit-at-a-time measurements (latency, Cholesky-only rate, stage split) and the '
+                         'ceiling microbenchmarks: every kernel of the process is then one of the timed configuration '
+                         '(for the rocprofv3 --stats / --pmc passes committed under profiles/)')
     ap.add_argument('--batch', type=int, default=-1,
                     help='c2 / c3: independent fits (distinct objects of the configured size) per launch sequence. '
                          'They go through the batched entry point (cgp_batch_fit, the path gaussian_process_nobject '
@@ -164,8 +165,8 @@ def main():
                          '--streams handles overlap whole fits instead)')
     ap.add_argument('--streams', type=int, default=0,
                     help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
-                         'buffers); 1 = strictly one fit at a time; 0 = auto: 4 for single-fit / sweep '
-                         'workloads, 1 for the batched one (its launches already span 128 fits)')
+                         'buffers); 0 = auto: 2 when c2 / c3 run in lock-step batches (--batch), 4 with --batch 1 and '
+                         'for the sweep, 1 for c4 (its launches already span 128 fits)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -311,8 +312,11 @@ def main():
 
     # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
     roof, extra = None, {}
-    if not batched and not args.no_extras:
-        ms_fit, st = dev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
+    if not batched:
+        # the update kernel exactly as it runs in the timed region: in lock-step mode one launch covers `lock` objects
+        # (the stage pass runs on a handle of the timed region), otherwise one object
+        rdev = all_devs[0] if lock > 1 else dev
+        ms_fit, st = rdev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
         ach = flops / (gemm_ms * 1e-3) / 1e12
@@ -324,15 +328,23 @@ def main():
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms', launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5),
-                    measured='HIP events around every launch, one fit at a time, eager launches '
-                             '(compare with the rocprofv3 summary of `bench.py --streams 1`)')
+                    objects_per_launch=lock,
+                    measured='HIP events around every launch of one eager pass over the %d objects of a launch '
+                             'sequence, on its stream (compare with the rocprofv3 summary of `bench.py --no-extras`)'
+                             % lock)
         if st[9] > 0:       # per tile form, to be matched against the per-kernel rows of rocprofv3 --stats
             roof['by_form'] = {
-                'k_gemm_nt<128,64,4,2,16>': dict(launches_per_fit=int(st[9]), avg_launch_ms=round(st[8] / st[9], 5),
+                'k_gemm_nt<128,64,4,2,16>': dict(launches=int(st[9]), avg_launch_ms=round(st[8] / st[9], 5),
                                                  achieved=round(st[10] / (st[8] * 1e-3) / 1e12, 3)),
-                'k_gemm_nt<64,64,2,4,16>': dict(launches_per_fit=int(launches - st[9]),
+                'k_gemm_nt<64,64,2,4,16>': dict(launches=int(launches - st[9]),
                                                 avg_launch_ms=round((gemm_ms - st[8]) / max(1., launches - st[9]), 5),
                                                 achieved=round((flops - st[10]) / ((gemm_ms - st[8]) * 1e-3) / 1e12, 3))}
+        if lock > 1:
+            roof['launches_per_pass'] = roof.pop('launches_per_fit')
+        if traffic is not None:
+            roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
+                                    'separate rocprofv3 passes, see profiles/')
+    if not batched and not args.no_extras:
         t_one = time.perf_counter()
         dev.bench_fit(3, stages=False)
         single_ms = (time.perf_counter() - t_one) * 1e3 / 3
@@ -344,17 +356,16 @@ def main():
         dev.bench_fit(5, stages=False)
         chol_ms = (time.perf_counter() - t_c) * 1e3 / 5
         dev.fit(wl['kp'], None, wl['xnew'], None, 0.) if wl['xnew'] is not None else None
+        ms_fit, st = dev.bench_fit(2, stages=True)     # stage split of ONE fit at a time (single-object handle)
         potrf_ms = st[1] + st[2] + st[3]
         chol_flops = n ** 3 / 3.0
         # the sweep also carries the M+1 tall rows (n^2 (m+1) flops): time share by flops
         sweep_flops = chol_flops + float(n) ** 2 * (wl['m'] + 1)
-        if traffic is not None:
-            roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
-                                    'separate rocprofv3 passes, see profiles/')
         extra = dict(single_fit_latency_ms=round(single_ms, 4),
                      single_fit_cholesky_ms=round(chol_ms, 4),
                      single_fit_cholesky_gflops=round(n ** 3 / 3.0 / (chol_ms * 1e-3) / 1e9, 1),
                      ms_per_fit_events=round(ms_fit, 4),
+                     single_fit_gemm_tflops=round(st[7] / (st[3] * 1e-3) / 1e12, 2),
                      stage_ms=dict(assemble_K=round(st[0], 4), potrf_diag=round(st[1], 4), trsm_panel=round(st[2], 4),
                                    gemm_update=round(st[3], 4), assemble_cross=round(st[4], 4), finish=round(st[5], 4)),
                      sweep_gflops=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),
@@ -362,10 +373,11 @@ def main():
                      assemble_K_GBs=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9, 1),
                      assemble_K_frac_of_hbm=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9 / SPEC_HBM_GBS, 4))
     if rank == 0:
-        mfma_tf, hbm_gbs = dev.microbench()
-        extra.update(measured_mfma_f64_ceiling_tflops=round(mfma_tf, 2), measured_hbm_write_gbs=round(hbm_gbs, 1))
-        if roof is not None:
-            roof['frac_of_measured_ceiling'] = round(roof['achieved'] / mfma_tf, 4)
+        if not args.no_extras:
+            mfma_tf, hbm_gbs = dev.microbench()
+            extra.update(measured_mfma_f64_ceiling_tflops=round(mfma_tf, 2), measured_hbm_write_gbs=round(hbm_gbs, 1))
+            if roof is not None:
+                roof['frac_of_measured_ceiling'] = round(roof['achieved'] / mfma_tf, 4)
         value = n_gpus * args.steps * units_per_step / elapsed
         line = dict(metric='gp_fits_per_sec', value=round(value, 4), unit='fits/s', n_gpus=n_gpus,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),

@@ -2,9 +2,11 @@
 `bench.py --streams 1 --steps 1 --warmup 0 --no-cpu-baseline`) into profiles/<name>.json.
 FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section:
 on gfx950 it counts 16-B-per-lane loads at half their bytes).
-usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv fits_in_run out.json"""
+Every update launch of the run is counted (setup, warm-up, timed steps, stage pass: all the same kernels on the
+same shapes), traffic is reported PER LAUNCH like the roofline's flops.
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv objects_per_launch out.json"""
 import csv, json, sys, collections
-fetch_csv, write_csv, fits, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+fetch_csv, write_csv, objs, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
 
 def load(path, counter):
     tot = collections.defaultdict(float); calls = collections.defaultdict(int)
@@ -17,19 +19,22 @@ def load(path, counter):
 f, fc = load(fetch_csv, 'FETCH_SIZE')
 w, wc = load(write_csv, 'WRITE_SIZE')
 gemm = [k for k in f if 'k_gemm_nt' in k]
-launches = sum(fc[k] for k in gemm) / fits
-fetch_b = 2. * 1024. * sum(f[k] for k in gemm) / fits
-write_b = 1024. * sum(w[k] for k in w if 'k_gemm_nt' in k) / fits
+launches = sum(fc[k] for k in gemm)
+wl = sum(wc[k] for k in w if 'k_gemm_nt' in k)
+fetch_b = 2. * 1024. * sum(f[k] for k in gemm) / launches
+write_b = 1024. * sum(w[k] for k in w if 'k_gemm_nt' in k) / wl
 asm = [k for k in f if 'k_assemble_train' in k]
-res = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --streams 1 --steps 1 '
-                  '--warmup 0 --no-cpu-baseline`; values per fit = totals / %g fits in the run; FETCH_SIZE doubled per '
-                  'MI355X_MICROARCH.md HBM section (16-B-per-lane loads on gfx950)' % fits,
-           kernel='k_gemm_nt (all launches of one fit, both tile forms)', launches_per_fit=launches,
-           fetch_bytes_per_fit=fetch_b, write_bytes_per_fit=write_b,
-           traffic_bytes_per_launch=(fetch_b + write_b) / launches,
-           assemble_train_write_bytes=1024. * sum(w[k] for k in w if 'k_assemble_train' in k) / fits,
-           assemble_train_fetch_bytes=2. * 1024. * sum(f[k] for k in asm) / fits,
+na = max(1, sum(fc[k] for k in asm))
+res = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`; all update '
+                  'launches of the run averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (16-B-per-lane '
+                  'loads on gfx950)',
+           kernel='k_gemm_nt (every launch of the run, both tile forms)', objects_per_launch=objs,
+           launches_in_run=launches, fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b,
+           traffic_bytes_per_launch=fetch_b + write_b,
+           fetch_bytes_per_fit=fetch_b * 63 / objs, write_bytes_per_fit=write_b * 63 / objs,
+           assemble_train_write_bytes_per_launch=1024. * sum(w[k] for k in w if 'k_assemble_train' in k) / na,
+           assemble_train_fetch_bytes_per_launch=2. * 1024. * sum(f[k] for k in asm) / na,
            per_kernel_KB_total_in_run=dict(FETCH_SIZE={k: f[k] for k in f}, WRITE_SIZE={k: w[k] for k in w}),
            calls_in_run={k: fc[k] for k in fc})
 json.dump(res, open(out, 'w'), indent=1)
-print(json.dumps({k: res[k] for k in ('launches_per_fit', 'fetch_bytes_per_fit', 'write_bytes_per_fit', 'traffic_bytes_per_launch')}))
+print(json.dumps({k: res[k] for k in ('launches_in_run', 'fetch_bytes_per_launch', 'write_bytes_per_launch', 'traffic_bytes_per_launch', 'fetch_bytes_per_fit')}))
