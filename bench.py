@@ -190,8 +190,15 @@ def main():
     dev.selftest_mfma()
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
-    lock = 1 if (batched or 'sweep' in wl) else (8 if args.batch < 0 else max(1, args.batch))
+    if batched:
+        lock = 1
+    elif 'sweep' in wl:
+        lock = len(wl['sweep']) if args.batch < 0 else max(1, args.batch)      # candidates per launch sequence
+    else:
+        lock = 8 if args.batch < 0 else max(1, args.batch)                     # objects per launch sequence
     nstreams = args.streams if args.streams > 0 else (1 if batched else (2 if lock > 1 else 4))
+    if 'sweep' in wl and args.streams <= 0:
+        nstreams = 1 if lock > 1 else 4
     # Independent fits are the unit of this path (objects, candidates): with several in flight the
     # latency-bound leaf chain of one fit runs in the gaps of the others' bulk updates.  Every handle has
     # its own stream and its own copy of the inputs in HBM; each fit is still one full pass.
@@ -242,7 +249,7 @@ def main():
         units_per_step = 1
 
     def sync_all():
-        for d in set([dev] + extra_devs + (fit_devs if lock > 1 else [])):
+        for d in set([dev] + extra_devs + (fit_devs if (lock > 1 and 'sweep' not in wl) else [])):
             d._lib.cgp_synchronize(d._h)
         if dist is not None:
             import torch
@@ -250,7 +257,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    all_devs = fit_devs if lock > 1 else [dev] + extra_devs
+    all_devs = fit_devs if (lock > 1 and 'sweep' not in wl) else [dev] + extra_devs
 
     stagger_s = float(os.environ.get('CGP_BENCH_STAGGER_MS', '0')) * 1e-3
 
@@ -259,7 +266,16 @@ def main():
             time.sleep(stagger_s * slot)
         # k device-resident fits (or batches of fits) back to back on this handle's stream, then sync:
         # the last cgp_fit / cgp_batch_fit left every input in HBM
-        if 'sweep' in wl:
+        if 'sweep' in wl and lock > 1:
+            # lock-step sweep: up to `lock` candidates per launch sequence (cgp_sweep_loglik: 7 doubles per candidate
+            # go down, 1 comes back, data resident and shared)
+            i = 0
+            while i < k:
+                c = min(lock, k - i)
+                ll_, info_ = d.sweep_loglik(np.array([kps[(offset + i + j) % len(kps)] for j in range(c)]), None)
+                assert not info_.any()
+                i += c
+        elif 'sweep' in wl:
             # one hyper-parameter set per evaluation: 7 doubles go down, 1 comes back (data resident)
             for i in range(k):
                 d.fit(kps[(offset + i) % len(kps)], None)
@@ -287,7 +303,7 @@ def main():
         for t in ths:
             t.join()
 
-    if lock > 1:
+    if lock > 1 and 'sweep' not in wl:
         # capture the launch graph of the partial pass each handle will need (k % lock objects) outside the timed region
         for i, d in enumerate(all_devs):
             k_i = args.steps // len(all_devs) + (1 if i < args.steps % len(all_devs) else 0)
@@ -315,7 +331,7 @@ def main():
     if not batched:
         # the update kernel exactly as it runs in the timed region: in lock-step mode one launch covers `lock` objects
         # (the stage pass runs on a handle of the timed region), otherwise one object
-        rdev = all_devs[0] if lock > 1 else dev
+        rdev = all_devs[0] if (lock > 1 and 'sweep' not in wl) else dev
         ms_fit, st = rdev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
@@ -341,10 +357,13 @@ def main():
                                                 achieved=round((flops - st[10]) / ((gemm_ms - st[8]) * 1e-3) / 1e12, 3))}
         if lock > 1:
             roof['launches_per_pass'] = roof.pop('launches_per_fit')
+        roof['objects_per_launch'] = lock
         if traffic is not None:
             roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
                                     'separate rocprofv3 passes, see profiles/')
     if not batched and not args.no_extras:
+        if 'sweep' in wl:
+            dev.fit(kps[0], None)                    # back to one candidate at a time on this handle
         t_one = time.perf_counter()
         dev.bench_fit(3, stages=False)
         single_ms = (time.perf_counter() - t_one) * 1e3 / 3

@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
-    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_sweep_loglik', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 
@@ -71,6 +71,7 @@ def load_library():
         lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
                                       _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
+        lib.cgp_sweep_loglik.argtypes = [vp, _i64, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int32)]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
         lib.cgp_bench_fit_objects.argtypes = [vp, ctypes.c_int, _i64, _dp]
         lib.cgp_microbench.argtypes = [vp, _dp, _dp]
@@ -306,6 +307,22 @@ class Device(object):
         all objects, or (B, m,[2]) with xnew_per_object=True."""
         self.batch_set_data(dim, xs, resids, diags)
         return self.batch_fit_resident(kp, xnew, mean_new, kss_noise, xnew_per_object)
+
+    def sweep_loglik(self, kps, diag=None):
+        """Log-likelihood of the resident object for every row of kps (P, 7) in one launch sequence.
+        Returns (loglik[P], info[P]).  Invalidates the resident batch of this handle."""
+        kps = _f64(kps)
+        if kps.ndim != 2 or kps.shape[1] != 7:
+            raise ValueError('kps must have shape (P, 7)')
+        dg = None if diag is None else _f64(diag, (self.n,))
+        P = kps.shape[0]
+        ll = np.empty(P)
+        info = np.zeros(P, dtype=np.int32)
+        self.batch_generation += 1
+        st = self._lib.cgp_sweep_loglik(self._h, P, _ptr(kps), _ptr(dg), _ptr(ll),
+                                        info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        self._check(st, 'cgp_sweep_loglik')
+        return ll, info
 
     # ---- measurement ---------------------------------------------------------------
     def bench_fit(self, iters, stages=True):

@@ -33,6 +33,7 @@ constexpr int NB = CGP_NB;
 #ifndef GEMM_KB_SMALL
 #define GEMM_KB_SMALL 16
 #endif
+constexpr long CGP_MAX_SWEEP = 256;     // candidates per cgp_sweep_loglik call
 constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144) * sizeof(double);
 
 inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
@@ -65,6 +66,7 @@ struct Prob {
     // tri_base + t stays zero left of column t), so a step that ends at column c only touches rows below
     // tri_base + c.
     long wrow0 = -1, zrow = -1, tri_base = -1;
+    int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
     long w0() const { return wrow0 >= 0 ? wrow0 : Np; }
     long zr() const { return zrow >= 0 ? zrow : R - 1; }
     long rend(long Rfull, long c_end) const { return tri_base >= 0 ? std::min(Rfull, tri_base + c_end) : Rfull; }
@@ -397,10 +399,10 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
 
 template <int DIM>
 int launch_assemble_train_t(cgp_handle* h, int B, double* M, long ld, long sM, const double* x, long sx,
-                            const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2) {
+                            const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2, int kps) {
     dim3 g((unsigned)(Np / 128), (unsigned)(Np / 64), (unsigned)B);
     hipLaunchKernelGGL((k_assemble_train<DIM>), g, dim3(256), 0, h->stream, M, ld, sM, x, sx, diag, sd, ns,
-                       (const KParams*)h->bkp.p, lower_only ? 1 : 0, use_nug2 ? 1 : 0);
+                       (const KParams*)h->bkp.p, lower_only ? 1 : 0, use_nug2 ? 1 : 0, kps);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -408,20 +410,20 @@ int launch_assemble_train_t(cgp_handle* h, int B, double* M, long ld, long sM, c
 // use_nug2: add kp.nug2 to the diagonal vector (the training matrix of a fit); false for K(new,new),
 // whose diagonal term is passed explicitly
 int launch_assemble_train(cgp_handle* h, int dim, int B, double* M, long ld, long sM, const double* x, long sx,
-                          const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2) {
-    return dim == 1 ? launch_assemble_train_t<1>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2)
-                    : launch_assemble_train_t<2>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2);
+                          const double* diag, long sd, const int* ns, long Np, bool lower_only, bool use_nug2, int kps = 0) {
+    return dim == 1 ? launch_assemble_train_t<1>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2, kps)
+                    : launch_assemble_train_t<2>(h, B, M, ld, sM, x, sx, diag, sd, ns, Np, lower_only, use_nug2, kps);
 }
 
 int launch_assemble_cross(cgp_handle* h, int dim, int B, double* Mrows, long ld, long sM, const double* x, long sx,
-                          const double* xnew, long sxn, const int* ns, long Np, long Mp, long m) {
+                          const double* xnew, long sxn, const int* ns, long Np, long Mp, long m, int kps = 0) {
     dim3 g((unsigned)(Np / 128), (unsigned)(Mp / 64), (unsigned)B);
     if (dim == 1)
         hipLaunchKernelGGL((k_assemble_cross<1>), g, dim3(256), 0, h->stream, Mrows, ld, sM, x, sx, xnew, sxn, ns,
-                           (const KParams*)h->bkp.p, (int)m);
+                           (const KParams*)h->bkp.p, (int)m, kps);
     else
         hipLaunchKernelGGL((k_assemble_cross<2>), g, dim3(256), 0, h->stream, Mrows, ld, sM, x, sx, xnew, sxn, ns,
-                           (const KParams*)h->bkp.p, (int)m);
+                           (const KParams*)h->bkp.p, (int)m, kps);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -433,7 +435,7 @@ int launch_finish(cgp_handle* h, Prob& P, long m, bool with_loglik, bool has_mea
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(k_finish, dim3((unsigned)blocks, 1, P.B), dim3(256), 0, h->stream, P.M, P.Np, P.sM, (int)P.Np,
                        (int)P.w0(), (int)P.zr(), (int)m, has_mean ? P.mean : nullptr, (const KParams*)h->bkp.p,
-                       P.ldp, P.sLd, (int)(P.Np / NB), P.ns, P.mu, P.var, P.sOut, P.scal);
+                       P.ldp, P.sLd, (int)(P.Np / NB), P.ns, P.mu, P.var, P.sOut, P.scal, P.kps);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -522,7 +524,7 @@ int begin_call(cgp_handle* h) {
     h->err.clear();
     HIPCHK(hipSetDevice(h->device));
     CHK(leaf_attr_once(h));
-    CHK(ensure(h, h->bkp, sizeof(KParams)));
+    CHK(ensure(h, h->bkp, CGP_MAX_SWEEP * sizeof(KParams)));   // [0] = the shared set; a sweep uses one per candidate
     return 0;
 }
 
@@ -587,13 +589,13 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int) * P.B, h->stream));
     {
         StageScope sc(h, ST_ASM_K);
-        CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true));
+        CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true, P.kps));
     }
     {
         StageScope sc(h, ST_ASM_H);
         // cross rows t < m; rows t >= m are zeros; then the residual row at R-1
         CHK(launch_assemble_cross(h, P.dim, P.B, P.M + P.Np * ld, ld, P.sM, P.x, P.sx, P.xnew, P.sxn, P.ns, P.Np, Mp,
-                                  m));
+                                  m, P.kps));
         CHK(put_resid_row(h, P));
     }
     if (h->trk.active) {
@@ -624,7 +626,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     if (!h->use_graph || h->profiling || getenv("CGP_NO_GRAPH")) return device_fit_eager(h, P, m, has_mean);
     cgp_handle::GraphKey key;
     std::memset(&key, 0, sizeof(key));
-    const void* ptrs[16] = {P.M, P.x, P.r, P.diag, P.xnew, nullptr, P.wsW, P.ldp, P.info, P.ns, P.mean, P.mu, P.var,
+    const void* ptrs[16] = {P.M, P.x, P.r, P.diag, P.xnew, (const void*)(intptr_t)(P.kps + 2 * (P.sx == 0)), P.wsW, P.ldp, P.info, P.ns, P.mean, P.mu, P.var,
                             P.scal, h->bkp.p, nullptr};
     std::memcpy(key.ptrs, ptrs, sizeof(ptrs));
     key.B = P.B; key.Np = P.Np; key.R = P.R; key.m = m; key.dim = P.dim; key.has_mean = has_mean ? 1 : 0;
@@ -1231,6 +1233,71 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     return CGP_OK;
 }
 
+// Log-likelihood of the resident object (cgp_fit_set_data) for P kernel-parameter sets in ONE launch sequence:
+// P matrices in HBM, coordinates / residual / diagonal shared (batch strides 0), one KParams per candidate.
+int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double* diag, double* loglik, int32_t* info) {
+    CHK(begin_call(h));
+    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_sweep_loglik: no data (call cgp_fit_set_data)");
+    if (np_ <= 0 || np_ > CGP_MAX_SWEEP || !kp || !loglik) return fail(h, CGP_E_ARG, "cgp_sweep_loglik: bad argument");
+    const long B = np_;
+    Prob& Q = h->Q;
+    h->have_batch = false;                     // the resident batch (if any) loses its buffers
+    Q = Prob();
+    Q.B = (int)B; Q.dim = h->P.dim; Q.n = h->P.n; Q.Np = h->P.Np;
+    Q.R = Q.Np + NB;
+    Q.sM = Q.R * Q.Np;
+    Q.kps = 1;
+    const long Np = Q.Np, nblk = Np / NB;
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
+    CHK(ensure(h, h->qinfo, B * sizeof(int)));
+    CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
+    CHK(ensure(h, h->qmu, (size_t)B * NB * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * NB * sizeof(double)));
+    CHK(ensure(h, h->qns, B * sizeof(int)));
+    CHK(upload_padded(h, h->qxnew, nullptr, 0, (size_t)NB * Q.dim));
+    if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)Q.n, (size_t)Np));
+    std::vector<KParams> ks(B);
+    std::vector<int> hn(B, (int)Q.n);
+    for (long b = 0; b < B; ++b) {
+        const double* k = kp + 7 * b;
+        ks[b].amp_train = k[0]; ks[b].amp_cross = k[1]; ks[b].p0 = k[2]; ks[b].p1 = k[3]; ks[b].p2 = k[4]; ks[b].p3 = k[5];
+        ks[b].nug2 = k[6]; ks[b].kss_noise = 0.;
+    }
+    HIPCHK(hipMemcpyAsync(h->bkp.p, ks.data(), B * sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    Q.M = (double*)h->qM.p;
+    Q.x = (double*)h->bx.p; Q.sx = 0;
+    Q.r = (double*)h->br.p; Q.sr = 0;
+    Q.diag = (double*)h->bdiag.p; Q.sd = 0;
+    Q.xnew = (double*)h->qxnew.p; Q.sxn = 0;
+    Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
+    Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
+    Q.info = (int*)h->qinfo.p;
+    Q.ns = (int*)h->qns.p;
+    Q.mean = nullptr;
+    Q.mu = (double*)h->qmu.p; Q.var = (double*)h->qvar.p; Q.sOut = NB;
+    Q.scal = (double*)h->qscal.p;
+    CHK(device_fit(h, Q, 0, false));
+    std::vector<double> sc((size_t)B * 2);
+    std::vector<int> hinfo(B);
+    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (long b = 0; b < B; ++b) {
+        loglik[b] = sc[2 * b];
+        if (info) info[b] = hinfo[b];
+    }
+    h->last_was_batch = true;
+    h->last_m = 0;
+    h->last_has_mean = false;
+    h->last_kss_noise = 0.;
+    h->factored = false;
+    return CGP_OK;
+}
+
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms) {
     CHK(begin_call(h));
     if (iters <= 0 || !ms_per_fit) return fail(h, CGP_E_ARG, "cgp_bench_fit: bad argument");
@@ -1279,7 +1346,7 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
 int cgp_bench_fit_objects(cgp_handle* h, int iters, int64_t nobj, double* ms_per_pass) {
     CHK(begin_call(h));
     if (iters <= 0 || !ms_per_pass) return fail(h, CGP_E_ARG, "cgp_bench_fit_objects: bad argument");
-    if (!h->last_was_batch || !h->have_batch) return fail(h, CGP_E_STATE, "cgp_bench_fit_objects: run cgp_batch_fit first");
+    if (!h->last_was_batch) return fail(h, CGP_E_STATE, "cgp_bench_fit_objects: run cgp_batch_fit or cgp_sweep_loglik first");
     Prob& P = h->Q;
     if (nobj <= 0 || nobj > P.B) return fail(h, CGP_E_ARG, "cgp_bench_fit_objects: nobj outside the resident batch");
     const int Bfull = P.B;

@@ -93,7 +93,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void k_assemble_train(
     double* __restrict__ M, long ld, long sM, const double* __restrict__ x, long sx,
     const double* __restrict__ diag, long sd, const int* __restrict__ ns, const KParams* __restrict__ kpp,
-    int lower_only, int use_nug2) {
+    int lower_only, int use_nug2, int kps = 0) {
     const int b = blockIdx.z;
     const int col0 = blockIdx.x * 128, row0 = blockIdx.y * 64;
     if (lower_only && col0 > row0 + 63) return;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_assemble_train(
     M += (long)b * sM;
     x += (long)b * sx;
     diag += (long)b * sd;
-    const KParams kp = *kpp;
+    const KParams kp = kpp[(long)b * kps];          // kps = 1: one parameter set per object (hyper-parameter sweeps)
     __shared__ double rx[64 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64 * DIM) rx[tid] = x[(long)row0 * DIM + tid];
@@ -143,14 +143,14 @@ template <int DIM>
 __global__ __launch_bounds__(256) void k_assemble_cross(
     double* __restrict__ M, long ld, long sM, const double* __restrict__ x, long sx,
     const double* __restrict__ xnew, long sxn, const int* __restrict__ ns,
-    const KParams* __restrict__ kpp, int m) {
+    const KParams* __restrict__ kpp, int m, int kps = 0) {
     const int b = blockIdx.z;
     const int col0 = blockIdx.x * 128, row0 = blockIdx.y * 64;
     const int n = ns[b];
     M += (long)b * sM;
     x += (long)b * sx;
     xnew += (long)b * sxn;
-    const KParams kp = *kpp;
+    const KParams kp = kpp[(long)b * kps];
     __shared__ double rx[64 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64 * DIM) rx[tid] = xnew[(long)row0 * DIM + tid];
@@ -771,8 +771,9 @@ __global__ __launch_bounds__(256) void k_finish(
     const double* __restrict__ M, long ld, long sM, int Np, int wrow0, int zrow, int m,
     const double* __restrict__ mean_new, const KParams* __restrict__ kpp,
     const double* __restrict__ logdet_parts, long sLd, int nblk, const int* __restrict__ ns,
-    double* __restrict__ mu, double* __restrict__ var, long sOut, double* __restrict__ scal) {
+    double* __restrict__ mu, double* __restrict__ var, long sOut, double* __restrict__ scal, int kps = 0) {
     const int b = blockIdx.z, t = blockIdx.x;
+    kpp += (long)b * kps;
     M += (long)b * sM;
     const double* z = M + (long)zrow * ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -104,48 +104,48 @@ class Comm(object):
         return [full[u, :all_lens[u]].copy() for u in range(n_units)]
 
 
-def sweep_log_likelihood(gp, table, comm=None, svd_method=False, streams=4):
+#: HBM the candidates of one sweep launch sequence may occupy (P x (Np + 128) x Np x 8 bytes)
+SWEEP_BYTES_LIMIT = 48 << 30
+
+
+def sweep_log_likelihood(gp, table, comm=None, svd_method=False, streams=None):
     """Log-likelihood of `gp` for every hyper-parameter row of `table` (P x nhyp, plus a trailing
     nugget column when gp.fit_nugget) -- BASELINE config[4]: candidates are independent units.
-    Rank r evaluates its contiguous block on its own GPU with the data resident in HBM (only the 7-double
-    kernel-parameter block goes down per candidate, one double comes back) and ONE all_gather returns the
-    P values on every rank.  On each GPU `streams` candidates are in flight on separate handles
-    (single-object GPs on the Cholesky path; otherwise one at a time).  comm=None: single process."""
-    import threading
+    Rank r evaluates its contiguous block on its own GPU and ONE all_gather returns the P values on every
+    rank.  A single-object GP on the Cholesky route evaluates its candidates in LOCK-STEP: cgp_sweep_loglik
+    factors up to 256 candidate matrices in one launch sequence (data resident and shared, one 7-double
+    parameter block per candidate down, one double back), in chunks of SWEEP_BYTES_LIMIT; everything else
+    (several objects, svd_method=True) goes candidate by candidate.  A candidate whose matrix is not
+    positive definite raises numpy.linalg.LinAlgError like the serial loop.  comm=None: single process.
+    (`streams` is accepted for compatibility and ignored.)"""
     table = np.asarray(table, dtype=np.float64)
     n_units = len(table)
     mine = list(range(n_units)) if comm is None else comm.my_units(n_units)
     vals = np.zeros(len(mine))
-    pooled = (not svd_method and gp.N_sn == 1 and streams > 1 and len(mine) > 1
-              and getattr(gp, '_device', None) is None)
-    if pooled:
-        from . import _lib
+    if not svd_method and gp.N_sn == 1 and len(mine) > 0:
         from .gaussian_process import _kparams
-        devs = _lib.device_pool(min(streams, len(mine)))
-        for d in devs:
-            d.set_data(gp._dim, gp.Time[0], gp._resid(0))
-        gp._resident = None                      # the default handle's data were replaced
-        errors = []
-
-        def work(slot):
-            d = devs[slot]
-            first = True
-            try:
-                for pos in range(slot, len(mine), len(devs)):
-                    row = table[mine[pos]]
-                    hyp, nug = (row[:-1], row[-1]) if gp.fit_nugget else (row, gp.nugget)
-                    vals[pos] = d.fit(_kparams(gp._dim, hyp, nug), gp._diag(0) if first else None)[0]
-                    first = False
-            except Exception as exc:             # LinAlgError of one candidate must reach the caller
-                errors.append(exc)
-
-        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(devs))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        if errors:
-            raise errors[0]
+        dev = gp.device
+        if gp._resident != (dev.generation, 0):
+            dev.set_data(gp._dim, gp.Time[0], gp._resid(0))
+            gp._resident = (dev.generation, 0)
+        gp._factor_token = None
+        kps = np.empty((len(mine), 7))
+        for pos, k in enumerate(mine):
+            row = table[k]
+            hyp, nug = (row[:-1], row[-1]) if gp.fit_nugget else (row, gp.nugget)
+            kps[pos] = _kparams(gp._dim, hyp, nug)
+        n = len(gp.y[0])
+        npad = -(-n // 128) * 128
+        per = (npad + 128) * npad * 8
+        chunk = int(max(1, min(256, SWEEP_BYTES_LIMIT // per)))
+        diag = gp._diag(0)
+        for lo in range(0, len(mine), chunk):
+            ll, info = dev.sweep_loglik(kps[lo:lo + chunk], diag)
+            bad = np.nonzero(info)[0]
+            if len(bad):
+                raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite '
+                                            '(candidate %d)' % (info[bad[0]], mine[lo + bad[0]]))
+            vals[lo:lo + chunk] = ll
     else:
         saved_comm = gp.comm
         gp.comm = None                 # objects are NOT sharded here: candidates are

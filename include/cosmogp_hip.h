@@ -167,6 +167,14 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
                   const double* mean_new, double kss_noise, double* loglik, int32_t* info,
                   double* mu, double* var);
 
+/* Hyper-parameter sweep (BASELINE config[4]; the loop a caller would write around
+ * Gaussian_process.compute_log_likelihood, Gaussian_process.py:191-213): log-likelihood of the RESIDENT
+ * object (cgp_fit_set_data) for np kernel-parameter sets kp[np][7] in ONE launch sequence -- np matrices in
+ * HBM, coordinates / residual / diagonal shared.  np <= 256 per call; info[c] > 0: candidate c is not positive
+ * definite (its loglik is then meaningless).  Replaces the resident batch of the handle. */
+int cgp_sweep_loglik(cgp_handle* h, int64_t np, const double* kp, const double* diag,
+                     double* loglik, int32_t* info);
+
 /* ---- measurement hooks (bench.py / tests only) ------------------------------------- */
 
 /* Device-resident timing of the last cgp_fit / cgp_batch_fit: runs `iters` fits (or batches) back to back with

@@ -90,6 +90,20 @@ class FakeDevice(object):
         cov = _kernel_from_kp(self.dim, kp0)(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ inv @ H.T
         return ll, logdet, 0, mu, np.diag(cov).copy(), cov if want_cov else None
 
+    def sweep_loglik(self, kps, diag=None):
+        self.calls.append('sweep_loglik:%d' % len(kps))
+        self.batch_generation += 1
+        if diag is not None:
+            self.diag = np.array(diag)
+        ll = np.zeros(len(kps))
+        info = np.zeros(len(kps), dtype=np.int32)
+        for c, kp in enumerate(kps):
+            try:
+                ll[c] = self._one(self.dim, self.x, self.r, self.diag, kp, None, None, 0.)[0]
+            except np.linalg.LinAlgError:
+                info[c] = 1
+        return ll, info
+
     def fit_grad(self, kp, diag=None):
         """Moment sums of include/cosmogp_hip.h (cgp_fit_grad), from dense NumPy."""
         self.calls.append('fit_grad')

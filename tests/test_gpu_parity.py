@@ -609,9 +609,11 @@ def test_resident_diag_and_nugget_in_kp(cg):
     assert abs(ll_z - ref_z) <= 1e-11 * abs(ref_z)
 
 
-def test_sweep_concurrent_handles(cg):
-    """Hyper-parameter sweep with 4 candidates in flight on 4 handles equals the one-at-a-time sweep
-    bit for bit and the oracle to 1e-11."""
+def test_sweep_lockstep(cg):
+    """Hyper-parameter sweep: the candidates of a single-object GP are factored in lock-step by ONE launch
+    sequence (cgp_sweep_loglik, shared data, one kernel-parameter block per candidate).  Every value is
+    bit-identical to the candidate evaluated alone and equals the oracle to 1e-11; chunking by the HBM budget
+    changes nothing; a non-positive-definite candidate raises like the serial loop."""
     from cosmogp_amd import multigpu
     rng = np.random.default_rng(55)
     n = 900
@@ -620,15 +622,34 @@ def test_sweep_concurrent_handles(cg):
     e = np.full(n, 0.1)
     gp = cg.gaussian_process_2d(y, X, y_err=e)
     table = np.array([[s_, l_, l_, 0.] for s_ in (0.7, 1.0, 1.4) for l_ in (20., 35., 60.)])
-    a = multigpu.sweep_log_likelihood(gp, table, streams=4)
-    b = multigpu.sweep_log_likelihood(gp, table, streams=1)
-    assert np.array_equal(a, b)
+    a = multigpu.sweep_log_likelihood(gp, table)
+    alone = []
+    for row in table:
+        gp.compute_log_likelihood(row, svd_method=False)
+        alone.append(gp.log_likelihood[0])
+    assert np.array_equal(a, np.array(alone))
     for k in (0, 4, 8):
         ref = orc.log_likelihood_gp(y, X, 'RBF2D', table[k], 0., y_err=e, svd_method=False)[0]
         assert abs(a[k] - ref) <= 1e-11 * abs(ref)
-    # the GP object still works afterwards (its resident data were replaced by the pool)
-    gp.compute_log_likelihood(table[1], svd_method=False)
-    assert gp.log_likelihood[0] == a[1]
+    saved = multigpu.SWEEP_BYTES_LIMIT
+    try:
+        multigpu.SWEEP_BYTES_LIMIT = 4 * (1024 + 128) * 1024 * 8          # 4 candidates per launch sequence
+        b = multigpu.sweep_log_likelihood(gp, table)
+    finally:
+        multigpu.SWEEP_BYTES_LIMIT = saved
+    assert np.array_equal(a, b)
+    # nugget column + fitted-nugget convention
+    gp.fit_nugget = True
+    tn = np.array([[1.0, 35., 35., 0., 0.05], [1.0, 35., 35., 0., 0.2]])
+    c = multigpu.sweep_log_likelihood(gp, tn)
+    ref = orc.log_likelihood_gp(y, X, 'RBF2D', tn[1, :4], 0.2, y_err=e, svd_method=False)[0]
+    assert abs(c[1] - ref) <= 1e-11 * abs(ref)
+    gp.fit_nugget = False
+    # 1D, noise-free data: K is numerically singular for every candidate
+    x1 = np.linspace(0., 5., 200)
+    g1 = cg.gaussian_process(np.sin(x1), x1)
+    with pytest.raises(np.linalg.LinAlgError):
+        multigpu.sweep_log_likelihood(g1, np.array([[1., 2.], [1., 3.]]))
 
 
 def test_concurrent_handles_independent_fits(cg):
