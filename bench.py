@@ -328,7 +328,7 @@ def main():
 
     # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
     roof, extra = None, {}
-    if not batched:
+    if True:
         # the update kernel exactly as it runs in the timed region: in lock-step mode one launch covers `lock` objects
         # (the stage pass runs on a handle of the timed region), otherwise one object
         rdev = all_devs[0] if (lock > 1 and 'sweep' not in wl) else dev
@@ -347,7 +347,7 @@ def main():
                     objects_per_launch=lock,
                     measured='HIP events around every launch of one eager pass over the %d objects of a launch '
                              'sequence, on its stream (compare with the rocprofv3 summary of `bench.py --no-extras`)'
-                             % lock)
+                             % (wl['B'] if batched else lock))
         if st[9] > 0:       # per tile form, to be matched against the per-kernel rows of rocprofv3 --stats
             roof['by_form'] = {
                 'k_gemm_nt<128,64,4,2,16>': dict(launches=int(st[9]), avg_launch_ms=round(st[8] / st[9], 5),
@@ -355,9 +355,9 @@ def main():
                 'k_gemm_nt<64,64,2,4,16>': dict(launches=int(launches - st[9]),
                                                 avg_launch_ms=round((gemm_ms - st[8]) / max(1., launches - st[9]), 5),
                                                 achieved=round((flops - st[10]) / ((gemm_ms - st[8]) * 1e-3) / 1e12, 3))}
-        if lock > 1:
+        if lock > 1 or batched:
             roof['launches_per_pass'] = roof.pop('launches_per_fit')
-        roof['objects_per_launch'] = lock
+        roof['objects_per_launch'] = wl['B'] if batched else lock
         if traffic is not None:
             roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
                                     'separate rocprofv3 passes, see profiles/')
