@@ -287,22 +287,12 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
 
     CGP_STAMP(0);
-    // load the tiles on/below the block diagonal: all loads first (8 x 16 B in flight per thread)
-    {
-        constexpr int NCH = CGP_NB * (CGP_NB / 2) / CGP_K3_THREADS;
-        d2 tmp[NCH];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int idx = tid + k * CGP_K3_THREADS, r = idx >> 6, c = (idx & 63) * 2;
-            tmp[k] = (d2){0., 0.};
-            if ((c >> 4) <= (r >> 4)) tmp[k] = *(const d2*)(M + (long)r * ld + c);
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int idx = tid + k * CGP_K3_THREADS, r = idx >> 6, c = (idx & 63) * 2;
-            if ((c >> 4) <= (r >> 4)) *(d2*)(As + r * CGP_LDA + c) = tmp[k];
-        }
-    }
+    // load the block by direct global -> LDS loads: one wave instruction = one full row (128 doubles) into
+    // As[r][0..127]; the part right of the diagonal tile is never read
+    for (int r = wave; r < CGP_NB; r += CGP_K3_THREADS / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(M + (long)r * ld + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(As + r * CGP_LDA), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CGP_STAMP(1);
 
@@ -498,23 +488,13 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
         d2 t0 = *(const d2*)(Ap + jb * 16), t1 = *(const d2*)(Ap + jb * 16 + 2);
         S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
     }
-    // L_kk strictly-lower tiles -> LDS (all loads of a batch in flight before the LDS writes)
+    // L_kk -> LDS by direct global -> LDS loads (global_load_lds_dwordx4): one wave instruction moves one full
+    // row of the block (64 lanes x 16 B = 128 doubles) to Ls[r][0..127], all rows of a wave in flight at once.
+    // Only the strictly-lower tiles are read later; rows 0..15 have none (and host the wave-private X tiles).
     constexpr int K4T = 64 * K4W;
-#pragma unroll
-    for (int batch = 0; batch < 1024 / K4T; ++batch) {
-        d2 tmp[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int idx = tid + (batch * 8 + k) * K4T, r = idx >> 6, c = (idx & 63) * 2;
-            tmp[k] = (d2){0., 0.};
-            if ((c >> 4) < (r >> 4)) tmp[k] = *(const d2*)(Lg + (long)r * ld + c);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int idx = tid + (batch * 8 + k) * K4T, r = idx >> 6, c = (idx & 63) * 2;
-            if ((c >> 4) < (r >> 4)) *(d2*)(Ls + r * CGP_LDA + c) = tmp[k];
-        }
-    }
+    for (int r = 16 + wave; r < CGP_NB; r += K4W)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Lg + (long)r * ld + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(Ls + r * CGP_LDA), 16, 0, 0);
     {
         d2 w[1024 / K4T];
 #pragma unroll
@@ -522,6 +502,7 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
 #pragma unroll
         for (int k = 0; k < 1024 / K4T; ++k) *(d2*)(Ws + 2 * (tid + k * K4T)) = w[k];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CGP_STAMP(51);
 
