@@ -293,7 +293,7 @@ def main():
         total = k * (len(kps) if 'sweep' in wl else 1)
         share = [total // len(all_devs) + (1 if i < total % len(all_devs) else 0) for i in range(len(all_devs))]
         if len(all_devs) == 1:
-            return run_on(dev, share[0], 0)
+            return run_on(all_devs[0], share[0], 0)
         ths, off = [], 0
         for slot, (d, n_) in enumerate(zip(all_devs, share)):
             ths.append(threading.Thread(target=run_on, args=(d, n_, off, slot)))
