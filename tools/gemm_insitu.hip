@@ -705,7 +705,11 @@ int main(int argc, char** argv) {
         usleep(3000);
         hipEventRecord(e0, 0);
         for (int rep = 0; rep < NREP; ++rep) {
-            if (atoi(argv[4]) == 2)
+            if (atoi(argv[4]) == 3)
+                hipLaunchKernelGGL((k_gemm_nt_dl<128, 64, 2, 4>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
+            else if (atoi(argv[4]) == 4)
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 2, 4, 16, 0>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
+            else if (atoi(argv[4]) == 2)
                 hipLaunchKernelGGL((k_gemm_sp<128, 64, 4, 2>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
             else if (atoi(argv[4]) == 0)
                 hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
