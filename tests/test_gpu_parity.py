@@ -687,3 +687,36 @@ def test_concurrent_handles_independent_fits(cg):
         t.join()
     for o, r in zip(out, ref):
         assert o[0] == r[0] and o[1] == r[1] and np.array_equal(o[2], r[2]) and np.array_equal(o[3], r[3])
+
+
+def test_n32768_two_cluster_consistency(cg):
+    """Beyond BASELINE's largest size (index arithmetic past 2^31 bytes per matrix: 8.6 GB at N = 32768): two point
+    clusters so far apart that every cross-covariance underflows to exactly 0 make K block diagonal, so the
+    log-likelihood of the whole is the sum of the parts (each computed by an N = 16384 fit) and the predictions
+    near one cluster equal that cluster's own."""
+    rng = np.random.default_rng(77)
+    n = 16384
+    xa = np.sort(rng.uniform(0., 3000., n))
+    xb = np.sort(rng.uniform(1e6, 1e6 + 3000., n))
+    f = lambda x: np.sin(x / 7.) + 0.3 * np.cos(x / 1.3)
+    ya = f(xa) + 0.1 * rng.standard_normal(n)
+    yb = f(xb - 1e6) + 0.1 * rng.standard_normal(n)
+    e = np.full(n, 0.1)
+    hyp = [1.0, 2.0]
+    grid = np.linspace(100., 2900., 257)
+    ga = cg.gaussian_process(ya, xa, kernel='RBF1D', y_err=e)
+    ga.hyperparameters = hyp
+    ga.compute_log_likelihood(hyp, svd_method=False)
+    lla = ga.log_likelihood[0]
+    ga.get_prediction(new_binning=grid, COV=False, svd_method=False)
+    gb = cg.gaussian_process(yb, xb, kernel='RBF1D', y_err=e)
+    gb.compute_log_likelihood(hyp, svd_method=False)
+    llb = gb.log_likelihood[0]
+    gab = cg.gaussian_process(np.concatenate([ya, yb]), np.concatenate([xa, xb]), kernel='RBF1D',
+                              y_err=np.concatenate([e, e]))
+    gab.hyperparameters = hyp
+    gab.compute_log_likelihood(hyp, svd_method=False)
+    assert abs(gab.log_likelihood[0] - (lla + llb)) <= 1e-11 * abs(lla + llb)
+    gab.get_prediction(new_binning=grid, COV=False, svd_method=False)
+    np.testing.assert_allclose(gab.Prediction[0], ga.Prediction[0], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(gab.variance[0], ga.variance[0], rtol=0, atol=1e-10)
