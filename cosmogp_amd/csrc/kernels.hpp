@@ -578,7 +578,7 @@ template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
-    int tile_end = 0) {
+    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -609,9 +609,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     // Persistent tile loop: a launch with fewer workgroups than tiles walks the tile list with stride
     // gridDim.x (bulk updates are launched with <= 240 workgroups of this 1-per-CU kernel so that some
     // CUs stay free for the latency-critical leaf kernels of the other stream).
-    for (int bid = blockIdx.x + tile_skip; bid < ntot; bid += gridDim.x) {
+    // tab != nullptr: the launch grid walks a host-built tile list instead (XCD-aligned order, see launch_gemm);
+    // entries with x < 0 are padding
+    for (int bid = blockIdx.x + tile_skip; bid < (tab ? ntab : ntot); bid += gridDim.x) {
     int ti, tj;
-    {
+    if (tab) {
+        const int2 t = tab[bid];
+        if (t.x < 0) continue;
+        ti = t.x;
+        tj = t.y;
+    } else {
         // Block ids are dealt round-robin over the 8 XCDs; with the row-major tile order the tiles that
         // run together on one XCD span ~16 tile rows x 8 columns, i.e. 24 shared panels per 128 tiles.
         // (A contiguous chunk per XCD was measured WORSE: +15 % HBM fetch, same time.)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <map>
 #include <vector>
+#include <algorithm>
 #include <cstring>
 #include <unistd.h>
 // core-clock monitor: one lane samples (core cycles, 100 MHz wall ticks) every ~20 us until *stop != 0
@@ -577,6 +578,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_sp(
 }
 
 
+// XCD-aligned tile list: workgroup p runs on XCD p % 8; XCD x gets, in row-major order, the tiles whose column
+// tile index is congruent to x mod 8 (so it only ever touches 1/8 of the B panels, also in the triangular part)
+static std::vector<int2> build_tab(int nr, int nc, int tri, int RT) {
+    std::vector<std::vector<int2>> lists(8);
+    const int nt = nc / RT;
+    for (int ti = 0; ti < nr; ++ti) {
+        const int ncols = (tri && ti < nt) ? RT * (ti + 1) : nc;
+        for (int tj = 0; tj < ncols; ++tj) lists[tj & 7].push_back(make_int2(ti, tj));
+    }
+    size_t L = 0;
+    for (auto& l : lists) L = std::max(L, l.size());
+    std::vector<int2> tab(8 * L, make_int2(-1, -1));
+    for (int x = 0; x < 8; ++x)
+        for (size_t q = 0; q < lists[x].size(); ++q) tab[q * 8 + x] = lists[x][q];
+    return tab;
+}
+
 struct Upd { long a, c0, rows, cols, K; };
 static void plan(long c0, long c1, long R, std::vector<Upd>& out) {
     if (c1 - c0 <= 128) return;
@@ -705,7 +723,21 @@ int main(int argc, char** argv) {
         usleep(3000);
         hipEventRecord(e0, 0);
         for (int rep = 0; rep < NREP; ++rep) {
-            if (atoi(argv[4]) == 3)
+            if (atoi(argv[4]) >= 100000) {   // (mode 10RRCC: output 128*RR x 128*CC... ) generic: argv[4] = 100000 + 100 * (rows / 1024) + (cols / 1024), K = 4096, separate C
+                static double* Cb = nullptr; if (!Cb) hipMalloc(&Cb, (size_t)16384 * 16384 * 8);
+                const int rr = ((atoi(argv[4]) - 100000) / 100) * 1024, cc = ((atoi(argv[4]) - 100000) % 100) * 1024;
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3((rr / 128) * (cc / 64)), dim3(512), 0, 0, Cb, 16384L, 0L, M, M, ld, 0L, 4096, rr / 128, cc / 64, 0, -1.0, 1.0, 0, 0);
+                if (rep == NREP - 1) printf("[%d x %d x 4096: %d tiles] ", rr, cc, (rr / 128) * (cc / 64));
+            } else if (atoi(argv[4]) >= 1000) {   // 4096 x 4096 output (rows 4096.. of M), depth K = argv[4] (<= 8192), no triangle
+                const int KK = atoi(argv[4]);
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(32 * 64), dim3(512), 0, 0, M + 4096 * ld, ld, 0L, M, M, ld, 0L, KK, 32, 64, 0, -1.0, 1.0, 0, 0);
+            } else if (atoi(argv[4]) == 6) {   // plain square 4096 x 4096 x 4096, no triangle
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(32 * 64), dim3(512), 0, 0, M + 4096, ld, 0L, M, M, ld, 0L, 4096, 32, 64, 0, -1.0, 1.0, 0, 0);
+            } else if (atoi(argv[4]) == 5) {
+                static int2* dtab = nullptr; static int ntab = 0;
+                if (!dtab) { auto t = build_tab((int)nr, (int)nc, 1, 2); ntab = (int)t.size(); hipMalloc(&dtab, t.size() * sizeof(int2)); hipMemcpy(dtab, t.data(), t.size() * sizeof(int2), hipMemcpyHostToDevice); printf("table: %d entries for %ld tiles\n", ntab, tiles); }
+                hipLaunchKernelGGL((k_gemm_nt<128, 64, 4, 2, 16, 0>), dim3(ntab), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0, 0, (const int2*)dtab, ntab);
+            } else if (atoi(argv[4]) == 3)
                 hipLaunchKernelGGL((k_gemm_nt_dl<128, 64, 2, 4>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
             else if (atoi(argv[4]) == 4)
                 hipLaunchKernelGGL((k_gemm_nt<128, 64, 2, 4, 16, 0>), dim3(tiles), dim3(512), 0, 0, M + u.a * ld + u.a, ld, 0L, M + u.a * ld + u.c0, M + u.a * ld + u.c0, ld, 0L, (int)u.K, (int)nr, (int)nc, 1, -1.0, 1.0, 0, 0);
@@ -722,7 +754,7 @@ int main(int argc, char** argv) {
         *stop = 1; hipStreamSynchronize(s2);
         std::vector<long long> ho(2 * maxn + 1); hipMemcpy(ho.data(), out, ho.size() * 8, hipMemcpyDeviceToHost);
         int n = (int)ho[2 * maxn];
-        printf("%d x K4096 update: %.3f ms each (%.1f TF); %d clock samples:\n", NREP, ms / NREP, 2.0 * 4096 * (0.5 * 4096 * 4097 + (double)(u.rows - 4096) * 4096) / (ms / NREP * 1e-3) / 1e12, n);
+        printf("%d x K4096 update: %.3f ms each (%.1f TF; as a square 4096^3: %.1f TF); %d clock samples:\n", NREP, ms / NREP, 2.0 * 4096 * (0.5 * 4096 * 4097 + (double)(u.rows - 4096) * 4096) / (ms / NREP * 1e-3) / 1e12, (atoi(argv[4]) >= 100000 ? 2.0 * 4096. * 1024. * ((atoi(argv[4]) - 100000) / 100) * 1024. * ((atoi(argv[4]) - 100000) % 100) : 2.0 * 4096. * 4096. * (atoi(argv[4]) >= 1000 ? atof(argv[4]) : 4096.)) / (ms / NREP * 1e-3) / 1e12, n);
         double t = 0;
         for (int i = 0; i < n; ++i) {
             t += ho[2 * i + 1] / 100.0;     // us
