@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
-    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_sweep_loglik', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_sweep_loglik', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 
@@ -71,6 +71,7 @@ def load_library():
         lib.cgp_batch_fit.argtypes = [vp, ctypes.c_int, _i64, ctypes.POINTER(_i64), _dp, _dp, _dp, _dp, _dp,
                                       _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
+        lib.cgp_batch_fit_grad.argtypes = [vp, _dp, _dp, ctypes.POINTER(ctypes.c_int32), _dp]
         lib.cgp_sweep_loglik.argtypes = [vp, _i64, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int32)]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
         lib.cgp_bench_fit_objects.argtypes = [vp, ctypes.c_int, _i64, _dp]
@@ -307,6 +308,19 @@ class Device(object):
         all objects, or (B, m,[2]) with xnew_per_object=True."""
         self.batch_set_data(dim, xs, resids, diags)
         return self.batch_fit_resident(kp, xnew, mean_new, kss_noise, xnew_per_object)
+
+    def batch_fit_grad_resident(self, kp):
+        """Log-likelihood and gradient moment sums of every object of the resident batch, one launch sequence.
+        Returns (loglik[B], info[B], sums[B, 5])."""
+        dim, B = self._batch
+        kp = _f64(kp, (7,))
+        ll = np.empty(B)
+        info = np.zeros(B, dtype=np.int32)
+        sums = np.zeros((B, 5))
+        st = self._lib.cgp_batch_fit_grad(self._h, _ptr(kp), _ptr(ll), info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                          _ptr(sums))
+        self._check(st, 'cgp_batch_fit_grad')
+        return ll, info, sums
 
     def sweep_loglik(self, kps, diag=None):
         """Log-likelihood of the resident object for every row of kps (P, 7) in one launch sequence.

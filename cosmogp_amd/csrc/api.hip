@@ -670,6 +670,46 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     return 0;
 }
 
+// Log-likelihood + gradient moment sums for the B objects of P (single object: B = 1, batch strides unused).
+// P must be bound with R = Np + (NB + Np) rows, mu / var of NB + Np doubles per object.  Results: P.scal
+// ([B][2] loglik, logdet), P.info, h->bgrad ([B][8], five sums each).
+int device_grad(cgp_handle* h, Prob& P) {
+    const long ld = P.Np, B = P.B;
+    CHK(ensure(h, h->bgrad, (size_t)B * 8 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int) * B, h->stream));
+    CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true, P.kps));
+    // tall rows: one block with the residual in its last row, then Np identity rows (triangular sweep)
+    P.zrow = P.Np + NB - 1;
+    P.wrow0 = P.tri_base = P.Np + NB;
+    HIPCHK(hipMemset2DAsync(P.M + P.Np * ld, (size_t)P.sM * sizeof(double), 0, (size_t)NB * ld * sizeof(double), B, h->stream));
+    CHK(put_resid_row(h, P));
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(256, 1, (unsigned)B), dim3(256), 0, h->stream, P.M + P.wrow0 * ld, ld,
+                       (int)P.Np, P.sM);
+    HIPCHK(hipGetLastError());
+    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    CHK(launch_finish(h, P, P.Np, true, false));            // mu := alpha = W z; scal := loglik, logdet
+    CHK(ensure(h, h->bC, (size_t)B * P.Np * P.Np * sizeof(double)));
+    CHK(launch_gemm(h, (int)B, (double*)h->bC.p, P.Np, P.Np * P.Np, P.M + P.wrow0 * ld, P.M + P.wrow0 * ld, ld, P.sM,
+                    P.Np, P.Np, P.Np, true, 1.0, 0.0, nullptr, 0, 0, true));
+    const dim3 g((unsigned)(P.Np / 128), (unsigned)(P.Np / 64), (unsigned)B);
+    const int nblocks = (int)(g.x * g.y);
+    CHK(ensure(h, h->bout, (size_t)B * nblocks * 8 * sizeof(double)));
+    if (P.dim == 1)
+        hipLaunchKernelGGL((k_grad_sums<1>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
+                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p,
+                           P.Np * P.Np, P.sOut, P.sx, P.kps);
+    else
+        hipLaunchKernelGGL((k_grad_sums<2>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
+                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p,
+                           P.Np * P.Np, P.sOut, P.sx, P.kps);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_grad_final, dim3((unsigned)B), dim3(256), 0, h->stream, (const double*)h->bout.p, nblocks,
+                       (double*)h->bgrad.p);
+    HIPCHK(hipGetLastError());
+    P.wrow0 = P.zrow = P.tri_base = -1;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -787,43 +827,16 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_fit_grad: no data (call cgp_fit_set_data)");
     if (!kp || !sums) return fail(h, CGP_E_ARG, "cgp_fit_grad: bad argument");
     Prob& P = h->P;
-    const long tall = P.Np + NB, ld = P.Np;
+    const long tall = P.Np + NB;
     CHK(bind_single(h, tall, false));
     CHK(upload_kp(h, kp, 0.));
     if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
     CHK(ensure(h, h->bmu, tall * sizeof(double)));
     CHK(ensure(h, h->bvar, tall * sizeof(double)));
-    CHK(ensure(h, h->bgrad, 8 * sizeof(double)));
     P.diag = (double*)h->bdiag.p;
     P.mean = nullptr;
     P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = tall;
-    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
-    CHK(launch_assemble_train(h, P.dim, 1, P.M, ld, P.sM, P.x, 0, P.diag, 0, P.ns, P.Np, true, true));
-    // tall rows: one block with the residual in its last row, then Np identity rows (triangular sweep)
-    P.zrow = P.Np + NB - 1;
-    P.wrow0 = P.tri_base = P.Np + NB;
-    HIPCHK(hipMemsetAsync(P.M + P.Np * ld, 0, (size_t)NB * ld * sizeof(double), h->stream));
-    CHK(put_resid_row(h, P));
-    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + P.wrow0 * ld, ld, (int)P.Np);
-    HIPCHK(hipGetLastError());
-    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
-    CHK(launch_finish(h, P, P.Np, true, false));            // mu := alpha = W z; scal := loglik, logdet
-    CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
-    CHK(launch_gemm(h, 1, (double*)h->bC.p, P.Np, 0, P.M + P.wrow0 * ld, P.M + P.wrow0 * ld, ld, 0, P.Np, P.Np, P.Np,
-                    true, 1.0, 0.0, nullptr, 0, 0, true));
-    P.wrow0 = P.zrow = P.tri_base = -1;
-    const dim3 g((unsigned)(P.Np / 128), (unsigned)(P.Np / 64), 1);
-    const int nblocks = (int)(g.x * g.y);
-    CHK(ensure(h, h->bout, (size_t)nblocks * 8 * sizeof(double)));
-    if (P.dim == 1)
-        hipLaunchKernelGGL((k_grad_sums<1>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
-                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p);
-    else
-        hipLaunchKernelGGL((k_grad_sums<2>), g, dim3(256), 0, h->stream, (const double*)h->bC.p, P.Np, (const double*)P.mu,
-                           (const double*)P.x, (const int*)P.ns, (const KParams*)h->bkp.p, (double*)h->bout.p);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_grad_final, dim3(1), dim3(256), 0, h->stream, (const double*)h->bout.p, nblocks, (double*)h->bgrad.p);
-    HIPCHK(hipGetLastError());
+    CHK(device_grad(h, P));
     double sc[2];
     int info = 0;
     HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -838,6 +851,57 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     h->last_has_mean = false;
     h->last_kss_noise = 0.;
     return info;
+}
+
+// The same for every object of the RESIDENT batch (cgp_batch_set_data) in one launch sequence; one kernel-parameter
+// set shared by the objects (the hyper-parameters of gaussian_process_nobject are common to its objects).
+int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t* info, double* sums) {
+    CHK(begin_call(h));
+    if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit_grad: no resident batch (call cgp_batch_set_data)");
+    if (!kp || !sums) return fail(h, CGP_E_ARG, "cgp_batch_fit_grad: bad argument");
+    Prob& Q = h->Q;
+    const long B = Q.B, Np = Q.Np, nblk = Np / NB, tall = Np + NB;
+    Q.R = Np + tall;
+    Q.sM = Q.R * Np;
+    Q.kps = 0;
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
+    CHK(ensure(h, h->qinfo, B * sizeof(int)));
+    CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
+    CHK(ensure(h, h->qmu, (size_t)B * tall * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * tall * sizeof(double)));
+    CHK(upload_kp(h, kp, 0.));
+    CHK(upload_padded(h, h->qxnew, nullptr, 0, (size_t)NB * Q.dim));
+    Q.M = (double*)h->qM.p;
+    Q.x = (double*)h->qx.p; Q.sx = Np * Q.dim;
+    Q.r = (double*)h->qr.p; Q.sr = Np;
+    Q.diag = (double*)h->qdiag.p; Q.sd = Np;
+    Q.xnew = (double*)h->qxnew.p; Q.sxn = 0;
+    Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
+    Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
+    Q.info = (int*)h->qinfo.p;
+    Q.ns = (int*)h->qns.p;
+    Q.mean = nullptr;
+    Q.mu = (double*)h->qmu.p; Q.var = (double*)h->qvar.p; Q.sOut = tall;
+    Q.scal = (double*)h->qscal.p;
+    CHK(device_grad(h, Q));
+    std::vector<double> sc((size_t)B * 2), gs((size_t)B * 8);
+    std::vector<int> hinfo(B);
+    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(gs.data(), h->bgrad.p, gs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (long b = 0; b < B; ++b) {
+        if (loglik) loglik[b] = sc[2 * b];
+        if (info) info[b] = hinfo[b];
+        for (int k = 0; k < 5; ++k) sums[5 * b + k] = gs[8 * b + k];
+    }
+    h->last_was_batch = true;
+    h->last_m = 0;
+    h->last_has_mean = false;
+    h->last_kss_noise = 0.;
+    return CGP_OK;
 }
 
 }  // extern "C"

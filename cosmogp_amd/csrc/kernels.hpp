@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void k_assemble_cross(
 
 // rows [row0, row0+nrows) := identity shifted so that row row0+i has its 1 in column i
 // (tall rows for the explicit inverse W = I L^-T)
-__global__ void k_set_identity_rows(double* __restrict__ M, long ld, int nrows) {
+__global__ void k_set_identity_rows(double* __restrict__ M, long ld, int nrows, long sM = 0) {
+    M += (long)blockIdx.z * sM;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long tot = (long)nrows * ld;
     for (; idx < tot; idx += (long)gridDim.x * blockDim.x) {
@@ -818,13 +819,20 @@ __global__ __launch_bounds__(256) void k_finish(
 template <int DIM>
 __global__ __launch_bounds__(256) void k_grad_sums(
     const double* __restrict__ Kinv, long ld, const double* __restrict__ alpha, const double* __restrict__ x,
-    const int* __restrict__ ns, const KParams* __restrict__ kpp, double* __restrict__ part) {
+    const int* __restrict__ ns, const KParams* __restrict__ kpp, double* __restrict__ part,
+    long sK = 0, long sAlpha = 0, long sx = 0, int kps = 0) {
+    const int bz = blockIdx.z;                 // object of a batch (strides 0 / grid.z = 1 for a single object)
+    Kinv += (long)bz * sK;
+    alpha += (long)bz * sAlpha;
+    x += (long)bz * sx;
+    kpp += (long)bz * kps;
+    part += (long)bz * gridDim.x * gridDim.y * 8;
     const int col0 = blockIdx.x * 128, row0 = blockIdx.y * 64;
     const int bl = blockIdx.y * gridDim.x + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[5] = {0., 0., 0., 0., 0.};
     __shared__ double rx[64 * 2], ra[64], red[4][5];
-    const int n = ns[0];
+    const int n = ns[bz];
     if (col0 <= row0 + 63 && row0 < n) {
         const KParams kp = *kpp;
         if (tid < 64 * DIM) rx[tid] = x[(long)row0 * DIM + tid];
@@ -877,6 +885,8 @@ __global__ __launch_bounds__(256) void k_grad_sums(
 
 // out[k] = sum over workgroup partials, fixed order (one workgroup)
 __global__ __launch_bounds__(256) void k_grad_final(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+    part += (long)blockIdx.x * nblocks * 8;    // one workgroup per object
+    out += (long)blockIdx.x * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ double red[4][5];
     double acc[5] = {0., 0., 0., 0., 0.};

@@ -194,13 +194,15 @@ class Gaussian_process(object):
             return list(range(self.N_sn))
         return self.comm.my_units(self.N_sn)
 
-    def _batch_chunks(self, objs):
-        """Split object indices into chunks whose padded batch fits BATCH_BYTES_LIMIT."""
+    def _batch_chunks(self, objs, grad=False):
+        """Split object indices into chunks whose padded batch fits BATCH_BYTES_LIMIT (the gradient needs
+        3 Np + 128 rows of Np doubles per object: K, the identity rows, K^-1)."""
         chunks, cur, cur_max = [], [], 0
         for sn in objs:
             n = len(self.y[sn])
             np_ = (max(cur_max, n) + 127) // 128 * 128
-            if cur and (len(cur) + 1) * (np_ + 128) * np_ * 8 > BATCH_BYTES_LIMIT:
+            rows = (3 * np_ + 128) if grad else (np_ + 128)
+            if cur and (len(cur) + 1) * rows * np_ * 8 > BATCH_BYTES_LIMIT:
                 chunks.append(cur)
                 cur, cur_max = [], 0
             cur.append(sn)
@@ -315,6 +317,24 @@ class Gaussian_process(object):
         dev = self.device
         objs = self._my_objects()
         rows = np.zeros((len(objs), 2 + nh))
+        from_sums = _kernel.gradient_from_sums_1d if self._dim == 1 else _kernel.gradient_from_sums_2d
+        if len(objs) > 1:
+            # objects in lock-step: one launch sequence per chunk of the batch (cgp_batch_fit_grad)
+            pos = 0
+            for chunk in self._batch_chunks(objs, grad=True):
+                self._batch_upload(chunk)
+                ll, info, sums = dev.batch_fit_grad_resident(kp)
+                bad = np.nonzero(info)[0]
+                if len(bad):
+                    raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
+                                                ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
+                for c in range(len(chunk)):
+                    g = from_sums(hyperparameter, Nugget, sums[c])
+                    rows[pos, 0] = ll[c]
+                    rows[pos, 1:1 + nh] = g[:nh]
+                    rows[pos, 1 + nh] = g[-1]
+                    pos += 1
+            objs = []
         for k, sn in enumerate(objs):
             diag = None
             if self._resident != (dev.generation, sn):

@@ -167,6 +167,11 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
                   const double* mean_new, double kss_noise, double* loglik, int32_t* info,
                   double* mu, double* var);
 
+/* cgp_fit_grad for every object of the RESIDENT batch (cgp_batch_set_data) in one launch sequence, one
+ * kernel-parameter set shared by the objects: loglik[B], info[B] (> 0: object not positive definite),
+ * sums[B][5] as in cgp_fit_grad. */
+int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t* info, double* sums);
+
 /* Hyper-parameter sweep (BASELINE config[4]; the loop a caller would write around
  * Gaussian_process.compute_log_likelihood, Gaussian_process.py:191-213): log-likelihood of the RESIDENT
  * object (cgp_fit_set_data) for np kernel-parameter sets kp[np][7] in ONE launch sequence -- np matrices in

@@ -90,6 +90,22 @@ class FakeDevice(object):
         cov = _kernel_from_kp(self.dim, kp0)(np.asarray(xnew, float), None, np.full(len(H), kss_noise)) - H @ inv @ H.T
         return ll, logdet, 0, mu, np.diag(cov).copy(), cov if want_cov else None
 
+    def batch_fit_grad_resident(self, kp):
+        dim, xs, resids, diags = self._b
+        self.calls.append('batch_fit_grad:%d' % len(xs))
+        B = len(xs)
+        ll, info, sums = np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros((B, 5))
+        keep = (getattr(self, 'dim', None), getattr(self, 'x', None), getattr(self, 'r', None), self.diag)
+        for b in range(B):
+            self.dim, self.x, self.r, self.n = dim, xs[b], resids[b], len(resids[b])
+            self.diag = None if diags is None else diags[b]
+            try:
+                ll[b], _, sums[b] = self.fit_grad(kp)
+            except np.linalg.LinAlgError:
+                info[b] = 1
+        self.dim, self.x, self.r, self.diag = keep
+        return ll, info, sums
+
     def sweep_loglik(self, kps, diag=None):
         self.calls.append('sweep_loglik:%d' % len(kps))
         self.batch_generation += 1

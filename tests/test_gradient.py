@@ -92,6 +92,7 @@ def test_host_chain_rule_with_fake_device():
     g = gq.compute_log_likelihood_gradient(h)
     ref = sum(orc.log_likelihood_gradient(ys[i], xs[i], 'RBF2D', h, 0., y_err=es[i], y_mean=0.) for i in range(3))
     np.testing.assert_allclose(g, ref[:4], rtol=1e-9, atol=1e-12)
+    assert gq.device.calls.count('batch_fit_grad:3') == 1          # the three objects went down in one launch sequence
     # the gradient-based search lands on the optimum of the derivative-free one (golden from the reference)
     gg = load_golden('fit_1d_n60')
     gp = cosmogp_amd.gaussian_process(gg['y'], gg['x'], kernel='RBF1D', y_err=gg['e'], device=FakeDevice())
@@ -156,9 +157,31 @@ def test_gpu_gradient_nobject_and_lbfgs_fit(cg):
     xs, ys, es = ([g['%s_%d' % (k, i)] for i in range(n)] for k in 'xye')
     gp = cg.gaussian_process_nobject(ys, xs, kernel='RBF1D', y_err=es)
     h = list(g['hyp'])
-    got = gp.compute_log_likelihood_gradient(h)
+    got = gp.compute_log_likelihood_gradient(h)                      # ragged 31 / 44 / 25: one batched launch sequence
     ref = sum(orc.log_likelihood_gradient(ys[i], xs[i], 'RBF1D', h, 0., y_err=es[i], y_mean=0.) for i in range(n))
     np.testing.assert_allclose(got, ref[:2], rtol=1e-8, atol=1e-8)
+    ll_batched = gp.log_likelihood.copy()
+    gp.compute_log_likelihood(h, svd_method=False)
+    assert np.array_equal(ll_batched, gp.log_likelihood)
+    # every object alone gives the same numbers bit for bit
+    alone = np.zeros(2)
+    for i in range(n):
+        g1 = cg.gaussian_process(ys[i], xs[i], kernel='RBF1D', y_err=es[i])
+        alone = alone + g1.compute_log_likelihood_gradient(h)
+    np.testing.assert_allclose(got, alone, rtol=1e-13)
+    # a larger, 2D batch (sizes 150 .. 400) and the joint L-BFGS-B fit of shared hyperparameters
+    rng = np.random.default_rng(9)
+    xs2, ys2, es2 = [], [], []
+    for k in (150, 260, 400, 333):
+        x = rng.uniform(0., 40., (k, 2))
+        e = rng.uniform(0.05, 0.1, k)
+        xs2.append(x); es2.append(e)
+        ys2.append(np.sin(x[:, 0] / 7.) * np.cos(x[:, 1] / 9.) + e * rng.standard_normal(k))
+    g2 = cg.gaussian_process_nobject(ys2, xs2, kernel='RBF2D', y_err=es2)
+    h2 = [0.9, 7., 8., 5.]
+    got2 = g2.compute_log_likelihood_gradient(h2)
+    ref2 = sum(orc.log_likelihood_gradient(ys2[i], xs2[i], 'RBF2D', h2, 0., y_err=es2[i], y_mean=0.) for i in range(4))
+    np.testing.assert_allclose(got2, ref2[:4], rtol=1e-8, atol=1e-8)
     gg = load_golden('fit_1d_n60')
     gp = cg.gaussian_process(gg['y'], gg['x'], kernel='RBF1D', y_err=gg['e'])
     gp.find_hyperparameters(hyperparameter_guess=list(gg['guess']), svd_method=False, method='L-BFGS-B')
