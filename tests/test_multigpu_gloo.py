@@ -71,6 +71,14 @@ def _worker(rank, world, port, out_dir):
     gp.compute_log_likelihood(g['hyp'], svd_method=False)
     assert gp.log_likelihood.shape == (1,)
     np.testing.assert_allclose(gp.log_likelihood, g['ll3_chol'], rtol=1e-11)
+    # analytic gradient of the joint likelihood: every rank reduces its own objects, one gather of (loglik, grad) rows
+    import importlib
+    orc_ = importlib.import_module('oracle.cosmogp_oracle')
+    grad = gp.compute_log_likelihood_gradient(g['hyp'])
+    want = sum(orc_.log_likelihood_gradient(ys[i], xs[i], 'RBF1D', g['hyp'], float(g['nugget']), y_err=es[i], y_mean=0.)
+               for i in range(n))
+    np.testing.assert_allclose(grad, want[:2], rtol=1e-9)
+    np.testing.assert_allclose(gp.log_likelihood, g['ll3_chol'], rtol=1e-11)
     # hyper-parameter sweep: candidates sharded over ranks, data resident, one gather
     table = np.array([[0.5, 6.], [0.6, 7.], [0.7, 8.], [0.8, 9.], [0.9, 10.]])
     gp1 = cosmogp_amd.gaussian_process(ys[0], xs[0], kernel='RBF1D', y_err=es[0], device=FakeDevice())
