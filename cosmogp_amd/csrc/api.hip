@@ -1241,6 +1241,8 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     const long Mp = round_up(m + 1, NB);
     Q.R = Q.Np + Mp;
     Q.sM = Q.R * Q.Np;
+    Q.kps = 0;                                  // one shared parameter set (a sweep may have left 1)
+    Q.wrow0 = Q.zrow = Q.tri_base = -1;
     const long Np = Q.Np, nblk = Np / NB;
     CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
     CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));

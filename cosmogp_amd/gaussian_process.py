@@ -36,11 +36,6 @@ from .mean import return_mean
 
 REFERENCE_STALE_INDEX = False
 
-#: Objects that cannot share one batched launch sequence (each has its own prediction grid) are fitted
-#: through this many handles at once (separate HIP streams and HBM buffers on the same GPU): the leaf
-#: chain of one fit runs in the gaps of the others.  1 = strictly one after the other.
-FITS_IN_FLIGHT = 4
-
 #: svd_method=True (the reference's default) means: pseudo-inverse from the decomposition of K with the
 #: modes whose singular value is <= 1e-15 dropped (inv_matrix.py:4-18).  How it is computed:
 #:   False   always by the device eigensolver (cgp_fit_svd), the reference's algorithm literally;
@@ -195,20 +190,20 @@ class Gaussian_process(object):
         return self.comm.my_units(self.N_sn)
 
     def _batch_chunks(self, objs, grad=False):
-        """Split object indices into chunks whose padded batch fits BATCH_BYTES_LIMIT (the gradient needs
-        3 Np + 128 rows of Np doubles per object: K, the identity rows, K^-1)."""
-        chunks, cur, cur_max = [], [], 0
+        """Split object indices into launch sequences: objects are bucketed by their padded size (multiples of
+        128), so that one large object does not inflate the matrices of the small ones, and a bucket is cut where
+        its batch would exceed BATCH_BYTES_LIMIT (the gradient needs 3 Np + 128 rows of Np doubles per object:
+        K, the identity rows, K^-1).  Chunks come largest size first; inside a chunk the object order is kept."""
+        buckets = {}
         for sn in objs:
-            n = len(self.y[sn])
-            np_ = (max(cur_max, n) + 127) // 128 * 128
+            buckets.setdefault((len(self.y[sn]) + 127) // 128 * 128, []).append(sn)
+        chunks = []
+        for np_ in sorted(buckets, reverse=True):
             rows = (3 * np_ + 128) if grad else (np_ + 128)
-            if cur and (len(cur) + 1) * rows * np_ * 8 > BATCH_BYTES_LIMIT:
-                chunks.append(cur)
-                cur, cur_max = [], 0
-            cur.append(sn)
-            cur_max = max(cur_max, n)
-        if cur:
-            chunks.append(cur)
+            per = max(1, int(BATCH_BYTES_LIMIT // (rows * np_ * 8)))
+            members = buckets[np_]
+            for lo in range(0, len(members), per):
+                chunks.append(members[lo:lo + per])
         return chunks
 
     def _fit_single(self, sn, kp, nugget, grid=None, new_y0=None, kss_noise=0.):
@@ -286,15 +281,17 @@ class Gaussian_process(object):
         kp = _kparams(self._dim, hyperparameter, nugget)
         if len(objs) == 1:
             return [self._fit_single(objs[0], kp, nugget)[0]]
-        out = []
+        where = {sn: k for k, sn in enumerate(objs)}
+        out = [0.] * len(objs)
         for chunk in self._batch_chunks(objs):
-            self._batch_upload(chunk)      # objects stay in HBM across objective evaluations
+            self._batch_upload(chunk)      # objects stay in HBM across objective evaluations (single-chunk case)
             ll, info, _, _ = dev.batch_fit_resident(kp)
             bad = np.nonzero(info)[0]
             if len(bad):
                 raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
                                             ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
-            out.extend(ll.tolist())
+            for c, sn in enumerate(chunk):
+                out[where[sn]] = float(ll[c])
         return out
 
     def compute_log_likelihood_gradient(self, Hyperparameter):
@@ -320,7 +317,7 @@ class Gaussian_process(object):
         from_sums = _kernel.gradient_from_sums_1d if self._dim == 1 else _kernel.gradient_from_sums_2d
         if len(objs) > 1:
             # objects in lock-step: one launch sequence per chunk of the batch (cgp_batch_fit_grad)
-            pos = 0
+            where = {sn: k for k, sn in enumerate(objs)}
             for chunk in self._batch_chunks(objs, grad=True):
                 self._batch_upload(chunk)
                 ll, info, sums = dev.batch_fit_grad_resident(kp)
@@ -328,12 +325,12 @@ class Gaussian_process(object):
                 if len(bad):
                     raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
                                                 ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
-                for c in range(len(chunk)):
+                for c, sn in enumerate(chunk):
                     g = from_sums(hyperparameter, Nugget, sums[c])
+                    pos = where[sn]
                     rows[pos, 0] = ll[c]
                     rows[pos, 1:1 + nh] = g[:nh]
                     rows[pos, 1 + nh] = g[-1]
-                    pos += 1
             objs = []
         for k, sn in enumerate(objs):
             diag = None
@@ -469,7 +466,7 @@ class Gaussian_process(object):
                     self.warning_pf = new_y0
                     self.Prediction[sn] = mu[k] + new_y0
                     self.variance[sn] = var[k]
-        elif len(objs) > 1 and self._own_grids_batchable(objs):
+        elif len(objs) > 1:
             # each object on its own grid, still ONE launch sequence per chunk: grids padded to the longest
             # (extra points repeat the last one and are dropped)
             for chunk in self._batch_chunks(objs):
@@ -487,8 +484,6 @@ class Gaussian_process(object):
                     self.warning_pf = new_y0
                     self.Prediction[sn] = mu[k, :len(grids[k])] + new_y0
                     self.variance[sn] = var[k, :len(grids[k])].copy()
-        elif len(objs) > 1 and FITS_IN_FLIGHT > 1 and self._device is None:
-            self._predict_pooled(objs, kp, kss_noise)
         else:
             for sn in objs:
                 new_y0 = self._new_y0(sn)
@@ -508,40 +503,6 @@ class Gaussian_process(object):
         if COV:
             self._cov_state = (kp, nugget, kss_noise)
             self.get_covariance_matrix()
-
-    def _own_grids_batchable(self, objs):
-        """Objects with their own grids go through one batched launch sequence when padding them to the largest
-        costs at most ~4x the flops of fitting each at its own size; very ragged sets are fitted one by one."""
-        pads = [(len(self.y[sn]) + 127) // 128 * 128 for sn in objs]
-        return len(objs) * max(pads) ** 3 <= 4 * sum(p ** 3 for p in pads)
-
-    def _predict_pooled(self, objs, kp, kss_noise):
-        """Per-object fits with own grids, FITS_IN_FLIGHT of them in flight on a pool of handles."""
-        import threading
-        devs = _lib.device_pool(min(FITS_IN_FLIGHT, len(objs)))
-        errors = []
-
-        def work(slot):
-            try:
-                for sn in objs[slot::len(devs)]:
-                    new_y0 = self._new_y0(sn)
-                    devs[slot].set_data(self._dim, self.Time[sn], self._resid(sn))
-                    _, _, mu, var = devs[slot].fit(kp, self._diag(sn), self._grid(sn), new_y0, kss_noise)
-                    self.Prediction[sn] = mu
-                    self.variance[sn] = var
-                    self.warning_pf = new_y0
-            except Exception as exc:           # e.g. LinAlgError of one object: re-raised by the caller
-                errors.append(exc)
-
-        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(devs))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        self._resident = None                  # the default handle (pool slot 0) now holds another object
-        self._factor_token = None
-        if errors:
-            raise errors[0]
 
     def get_covariance_matrix(self):
         """self.covariance_matrix = [K(new,new; nugget) - H K^-1 H^T] (Gaussian_process.py:340-361).

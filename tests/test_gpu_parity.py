@@ -720,3 +720,35 @@ def test_n32768_two_cluster_consistency(cg):
     gab.get_prediction(new_binning=grid, COV=False, svd_method=False)
     np.testing.assert_allclose(gab.Prediction[0], ga.Prediction[0], rtol=0, atol=1e-10)
     np.testing.assert_allclose(gab.variance[0], ga.variance[0], rtol=0, atol=1e-10)
+
+
+def test_nobject_mixed_sizes_are_bucketed(cg):
+    """One large object among small ones: objects are bucketed by padded size (three launch sequences here, not one
+    padded to 1024), results in object order, equal to every object fitted alone bit for bit."""
+    import sys
+    rng = np.random.default_rng(17)
+    sizes = [30, 900, 45, 200, 130, 60]
+    xs = [np.sort(rng.uniform(0., 0.3 * n + 5., n)) for n in sizes]
+    es = [rng.uniform(0.05, 0.2, n) for n in sizes]
+    ys = [np.sin(x / 3.) + e * rng.standard_normal(len(x)) for x, e in zip(xs, es)]
+    gp = cg.gaussian_process_nobject(ys, xs, kernel='RBF1D', y_err=es)
+    hyp = [0.9, 2.5]
+    gp.hyperparameters = hyp
+    chunks = gp._batch_chunks(list(range(6)))
+    assert sorted(map(sorted, chunks)) == [[0, 2, 5], [1], [3, 4]]
+    grid = np.linspace(0., 20., 33)
+    gp.get_prediction(new_binning=grid, svd_method=False)
+    gp.compute_log_likelihood(hyp, svd_method=False)
+    total = 0
+    for i in range(6):
+        g1 = cg.gaussian_process(ys[i], xs[i], kernel='RBF1D', y_err=es[i])
+        g1.hyperparameters = hyp
+        g1.get_prediction(new_binning=grid, svd_method=False)
+        assert np.array_equal(g1.Prediction[0], gp.Prediction[i]) and np.array_equal(g1.variance[0], gp.variance[i])
+        g1.compute_log_likelihood(hyp, svd_method=False)
+        total = total + g1.log_likelihood
+    assert np.array_equal(total, gp.log_likelihood)
+    gp.get_prediction(new_binning=None, svd_method=False)            # own grids, bucketed too
+    want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=None, svd_method=False)
+    for i in range(6):
+        np.testing.assert_allclose(gp.Prediction[i], want['prediction'][i], rtol=0, atol=1e-9)
