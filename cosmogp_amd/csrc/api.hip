@@ -113,6 +113,7 @@ struct cgp_handle {
     // captured device-side fit (hipGraph), replayed while shapes and buffers stay the same
     struct GraphKey {
         const void* ptrs[16];
+        long strides[6];         // sx, sr, sd, sxn, sM, sOut: same buffers with other strides are another graph
         long B, Np, R, m;
         int dim, has_mean;
         bool operator==(const GraphKey& o) const { return std::memcmp(this, &o, sizeof(GraphKey)) == 0; }
@@ -630,6 +631,8 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
                             P.scal, h->bkp.p, nullptr};
     std::memcpy(key.ptrs, ptrs, sizeof(ptrs));
     key.B = P.B; key.Np = P.Np; key.R = P.R; key.m = m; key.dim = P.dim; key.has_mean = has_mean ? 1 : 0;
+    key.strides[0] = P.sx; key.strides[1] = P.sr; key.strides[2] = P.sd; key.strides[3] = P.sxn;
+    key.strides[4] = P.sM; key.strides[5] = P.sOut;
     for (auto& g : h->graphs)
         if (g.key == key) {
             HIPCHK(hipGraphLaunch(g.exec, h->stream));

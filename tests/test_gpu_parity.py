@@ -752,3 +752,26 @@ def test_nobject_mixed_sizes_are_bucketed(cg):
     want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=None, svd_method=False)
     for i in range(6):
         np.testing.assert_allclose(gp.Prediction[i], want['prediction'][i], rtol=0, atol=1e-9)
+
+
+def test_shared_then_own_grids_same_shape(cg):
+    """Same batch, same number of prediction points, first one grid shared by all objects and then one grid per
+    object: the two launch graphs must not be confused (they differ only in a stride)."""
+    rng = np.random.default_rng(23)
+    n = 64
+    xs = [np.sort(rng.uniform(0., 20., n)) for _ in range(3)]
+    es = [np.full(n, 0.1) for _ in range(3)]
+    ys = [np.sin(x / 2.) + 0.1 * rng.standard_normal(n) for x in xs]
+    gp = cg.gaussian_process_nobject(ys, xs, kernel='RBF1D', y_err=es)
+    hyp = [1.0, 2.0]
+    gp.hyperparameters = hyp
+    shared = np.linspace(0., 20., n)                     # m == n: the own-grid call below has the same shapes
+    for _ in range(2):
+        gp.get_prediction(new_binning=shared, COV=False, svd_method=False)
+        want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=shared, svd_method=False, cov=False)
+        for i in range(3):
+            np.testing.assert_allclose(gp.Prediction[i], want['prediction'][i], rtol=0, atol=1e-10)
+        gp.get_prediction(new_binning=None, COV=False, svd_method=False)
+        want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=None, svd_method=False, cov=False)
+        for i in range(3):
+            np.testing.assert_allclose(gp.Prediction[i], want['prediction'][i], rtol=0, atol=1e-10)
