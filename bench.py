@@ -165,8 +165,8 @@ def main():
                          '--streams handles overlap whole fits instead)')
     ap.add_argument('--streams', type=int, default=0,
                     help='independent fits in flight per GPU (separate handles = separate HIP streams and HBM '
-                         'buffers); 0 = auto: 2 when c2 / c3 run in lock-step batches (--batch), 4 with --batch 1 and '
-                         'for the sweep, 1 for c4 (its launches already span 128 fits)')
+                         'buffers); 0 = auto: 2 when c2 / c3 run in lock-step batches (--batch), 4 with --batch 1, '
+                         '4 for c4 (232k -> 290k fits/s), 1 for the lock-step sweep')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -196,7 +196,7 @@ def main():
         lock = len(wl['sweep']) if args.batch < 0 else max(1, args.batch)      # candidates per launch sequence
     else:
         lock = 8 if args.batch < 0 else max(1, args.batch)                     # objects per launch sequence
-    nstreams = args.streams if args.streams > 0 else (1 if batched else (2 if lock > 1 else 4))
+    nstreams = args.streams if args.streams > 0 else (4 if batched else (2 if lock > 1 else 4))
     if 'sweep' in wl and args.streams <= 0:
         nstreams = 1 if lock > 1 else 4
     # Independent fits are the unit of this path (objects, candidates): with several in flight the
