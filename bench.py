@@ -402,10 +402,11 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                     config=dict(workload=wl['label'], n=wl['n'], m=wl['m'], dim=wl['dim'],
-                                fits_per_step_per_gpu=units_per_step, fits_in_flight_per_gpu=nstreams * lock,
-                                objects_per_launch_sequence=lock, handles_per_gpu=nstreams,
+                                fits_per_step_per_gpu=units_per_step,
+                                fits_in_flight_per_gpu=nstreams * (wl['B'] if batched else lock),
+                                objects_per_launch_sequence=(wl['B'] if batched else lock), handles_per_gpu=nstreams,
                                 parallelism='independent fits, 1 rank per GPU, %d handles (HIP streams) per GPU, '
-                                            '%d distinct objects per launch sequence' % (nstreams, lock)),
+                                            '%d distinct objects per launch sequence' % (nstreams, wl['B'] if batched else lock)),
                     roofline=roof)
         if n_gpus == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(wl)
