@@ -948,6 +948,20 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     hipLaunchKernelGGL(k_jac_identity, dim3(512), dim3(256), 0, h->stream, V, ld, (int)Np);
     HIPCHK(hipGetLastError());
     const int max_sweeps = 40;
+    if (n <= JP && !getenv("CGP_JAC_NO_SMALL")) {
+        // the whole problem is one pivot matrix: one launch
+        hipLaunchKernelGGL(k_jac_small, dim3(1), dim3(256), 0, h->stream, K, V, ld, (const JacStat*)st, 60);
+        HIPCHK(hipGetLastError());
+        h->last_sweeps = 1;
+        hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)K, (const double*)V,
+                           (double*)h->jVD.p, ld, (int)Np, (int)n, thresh, (double*)h->jlam.p, (double*)h->jres.p);
+        HIPCHK(hipGetLastError());
+        CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, (const double*)h->jVD.p, (const double*)h->jV.p, ld, 0, Np, Np, Np,
+                        true, 1.0, 0.0));
+        hipLaunchKernelGGL(k_mirror_lower, dim3(512), dim3(256), 0, h->stream, (double*)h->bC.p, ld, (int)Np);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // cyclic sweeps over a pivot matrix per visit: 1 (classical block-cyclic Jacobi) is the fastest -- the
     // number of outer sweeps (17-19 on RBF + noise matrices) does not go down when the pivots are
     // diagonalised further (measured: 12 -> 1 cuts N = 2048 from 500 to 270 ms)

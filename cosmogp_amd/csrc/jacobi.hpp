@@ -158,6 +158,88 @@ __global__ __launch_bounds__(256) void k_jac_inner(const double* __restrict__ K,
     }
 }
 
+// Small matrices (n <= 64): the whole problem is ONE pivot matrix.  A single workgroup diagonalises the leading
+// 64 x 64 block of K (identity-padded beyond n) in LDS until no rotation above the threshold is left, then writes
+// the eigenvalues onto the diagonal of K (off-diagonals of that block := 0) and V[0:64, 0:64] := Q.  Everything
+// outside the block is the identity padding already (V was initialised to I), so k_jac_finish and the K^+ GEMM run
+// unchanged.  Replaces (Np / 32 - 1) rounds x ~15 sweeps x 3 launches by one launch.
+__global__ __launch_bounds__(256) void k_jac_small(double* __restrict__ K, double* __restrict__ V, long ld,
+                                                   const JacStat* __restrict__ st, int max_sweeps) {
+    __shared__ __attribute__((aligned(16))) double S[JP * JLD];
+    __shared__ __attribute__((aligned(16))) double Q[JP * JLD];
+    __shared__ double rc[32], rs[32];
+    __shared__ int rp[32], rq[32];
+    __shared__ int any_sweep;
+    const int tid = threadIdx.x;
+    const double tol = st->tol;
+    for (int idx = tid; idx < JP * JP; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        S[r * JLD + c] = K[(long)r * ld + c];
+        Q[r * JLD + c] = (r == c) ? 1. : 0.;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) any_sweep = 0;
+        __syncthreads();
+        for (int step = 0; step < JP - 1; ++step) {
+            if (tid < 32) {
+                int p, q;
+                if (tid == 0) { p = step; q = JP - 1; }
+                else { p = (step + tid) % (JP - 1); q = (step - tid + (JP - 1)) % (JP - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                const double apq = S[p * JLD + q];
+                double c = 1., s = 0.;
+                if (fabs(apq) > tol) {
+                    const double tau = (S[q * JLD + q] - S[p * JLD + p]) / (2. * apq);
+                    const double t = (tau >= 0. ? 1. : -1.) / (fabs(tau) + sqrt(1. + tau * tau));
+                    c = 1. / sqrt(1. + t * t);
+                    s = t * c;
+                    any_sweep = 1;
+                }
+                rc[tid] = c; rs[tid] = s; rp[tid] = p; rq[tid] = q;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int item = tid + 256 * i, pr = item >> 6, col = item & 63;
+                const double s = rs[pr];
+                if (s != 0.) {
+                    const double c = rc[pr];
+                    const int p = rp[pr], q = rq[pr];
+                    const double a = S[p * JLD + col], b = S[q * JLD + col];
+                    S[p * JLD + col] = c * a - s * b;
+                    S[q * JLD + col] = s * a + c * b;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int item = tid + 256 * i, pr = item >> 6, row = item & 63;
+                const double s = rs[pr];
+                if (s != 0.) {
+                    const double c = rc[pr];
+                    const int p = rp[pr], q = rq[pr];
+                    double a = S[row * JLD + p], b = S[row * JLD + q];
+                    S[row * JLD + p] = c * a - s * b;
+                    S[row * JLD + q] = s * a + c * b;
+                    a = Q[row * JLD + p]; b = Q[row * JLD + q];
+                    Q[row * JLD + p] = c * a - s * b;
+                    Q[row * JLD + q] = s * a + c * b;
+                }
+            }
+            __syncthreads();
+        }
+        const int more = any_sweep;
+        __syncthreads();
+        if (!more) break;
+    }
+    for (int idx = tid; idx < JP * JP; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        K[(long)r * ld + c] = (r == c) ? S[r * JLD + r] : 0.;
+        V[(long)r * ld + c] = Q[r * JLD + c];
+    }
+}
+
 // E2 (MODE 0): X[IJ, c0:c0+64] <- Q' X[IJ, c0:c0+64]        grid (Np / 64, npairs, 1),     X = K
 // E3 (MODE 1): X[r0:r0+64, IJ] <- X[r0:r0+64, IJ] Q           grid (Np / 64, npairs, 2),     X = K, V
 // Both are  Y[a][b] = sum_s A[s][a] B[s][b]  on LDS tiles:  MODE 0: A = Q, B = X;  MODE 1: A = X^T, B = Q.

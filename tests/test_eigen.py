@@ -62,7 +62,7 @@ def test_svd_inverse_singular_properties(cg):
     np.testing.assert_allclose(K @ inv_t @ K, K, rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize('n', [37, 128, 200, 515])
+@pytest.mark.parametrize('n', [1, 2, 5, 37, 64, 65, 128, 200, 515])
 def test_svd_inverse_random_spd(cg, n):
     rng = np.random.default_rng(n)
     a = rng.standard_normal((n, n))
