@@ -2,10 +2,9 @@
 of the hot path).
 
 The reference re-builds a GP on N-1 points and predicts, N times per object, one after the
-other (pull.py:51-90: O(N^4)).  Here the N leave-one-out problems of an object are ONE
-batched launch sequence on the device (cgp_batch_fit with one prediction point per
-sub-problem), the per-subset mean offsets are the same host O(N) code as the reference.
-svd_method=True keeps the reference's host SVD route through the Gaussian_process class.
+other (pull.py:51-90: O(N^4)).  Here the leave-one-out problems of ALL objects are batched launch
+sequences on the device (cgp_batch_fit with one prediction point per sub-problem, bucketed by padded
+size), the per-subset mean offsets are the same host O(N) code as the reference.
 """
 import numpy as np
 from scipy.stats import norm as normal
@@ -43,79 +42,115 @@ class build_pull(object):
         self._device = device
 
     def compute_pull(self, diff=None, svd_method=True, substract_mean=False):
-        """Fill self.pull / self.residual / self.prediction (pull.py:43-102)."""
+        """Fill self.pull / self.residual / self.prediction (pull.py:43-102).
+
+        The leave-one-out sub-problems of ALL objects (sum of n_i of them) are bucketed by padded size and run as
+        batched launch sequences with one prediction point each.  svd_method=True (the reference's default) takes
+        the same batched Cholesky route whenever the noise diagonal proves that the pseudo-inverse is the inverse
+        (gaussian_process.SVD_VIA_CHOLESKY_WHEN_PD, 'auto' by default), otherwise -- or when a sub-matrix turns
+        out not to be positive definite -- the sub-problems go one by one through the device eigensolver route."""
         dev = self._device if self._device is not None else _lib.default_device()
         dim = 1 if self.kernel == 'RBF1D' else 2
+        objs = []
         for sn in range(self.n_object):
             y = np.asarray(self.y[sn], dtype=np.float64)
             x = np.asarray(self.x[sn], dtype=np.float64)
-            n = len(y)
             yerr = np.zeros_like(y) if self.y_err is None else np.asarray(self.y_err[sn], dtype=np.float64)
             dd = None if diff is None else diff[sn]
             if self.y_mean is None and substract_mean:                       # pull.py:71-73
                 self.y_mean = np.ones_like(y) * np.mean(y)
                 self.x_axis_mean = x
-            use_mean = substract_mean or self.y_mean is not None
-            if svd_method:
-                pred, pred_var = self._loo_host_svd(sn, y, x, yerr, dd, substract_mean)
-            else:
-                xs, rs, ds, offs = [], [], [], np.zeros(n)
-                for t in range(n):
-                    keep = np.ones(n, dtype=bool)
-                    keep[t] = False
-                    if use_mean:
-                        y0 = return_mean(y[keep], x[keep], mean_y=self.y_mean, mean_xaxis=self.x_axis_mean,
-                                         diff=dd)
-                        offs[t] = np.atleast_1d(return_mean(y[keep], x[keep], new_x=x, mean_y=self.y_mean,
-                                                            mean_xaxis=self.x_axis_mean, diff=dd)
-                                                * np.ones(n))[t]
-                    else:
-                        y0 = 0.
-                    xs.append(x[keep])
-                    rs.append(y[keep] - y0)
-                    ds.append(_kernel.diag_term(n - 1, yerr[keep], 0., 0.))
-                grids = x.reshape((n, 1) + x.shape[1:])                      # one point per sub-problem
-                # the n sub-problems go down in chunks whose padded batch fits the HBM budget
-                np_ = (n - 1 + 127) // 128 * 128
-                per = max(1, int(gpm.BATCH_BYTES_LIMIT // ((np_ + 128) * np_ * 8)))
-                pred, pred_var = np.zeros(n), np.zeros(n)
-                kp = _kparams(dim, self.hyperparameters, self.nugget)
-                for lo in range(0, n, per):
-                    hi = min(n, lo + per)
-                    _, info, mu, var = dev.batch_fit(dim, xs[lo:hi], rs[lo:hi], ds[lo:hi], kp, xnew=grids[lo:hi],
-                                                     kss_noise=0. ** 2 + 0. ** 2 + self.nugget ** 2,
-                                                     xnew_per_object=True)
-                    if np.any(info):
-                        raise np.linalg.LinAlgError('leave-one-out matrix %d is not positive definite'
-                                                    % (lo + int(np.nonzero(info)[0][0])))
-                    pred[lo:hi] = mu[:, 0] + offs[lo:hi]
-                    pred_var[lo:hi] = np.abs(var[:, 0])
+            objs.append((y, x, yerr, dd))
+        batched = not svd_method
+        if svd_method and gpm.SVD_VIA_CHOLESKY_WHEN_PD:
+            bound = min(float(np.min(o[2] ** 2)) if len(o[0]) else np.inf for o in objs) + float(self.nugget) ** 2
+            batched = gpm.SVD_VIA_CHOLESKY_WHEN_PD is True or bound > 1e-14
+        results = None
+        if batched:
+            try:
+                results = self._loo_batched(dev, dim, objs, substract_mean)
+            except np.linalg.LinAlgError:
+                if not svd_method:
+                    raise
+        if results is None:
+            results = [self._loo_svd(sn, o[0], o[1], o[2], o[3], substract_mean) for sn, o in enumerate(objs)]
+        for sn, (y, x, yerr, dd) in enumerate(objs):
+            pred, pred_var = results[sn]
             pull = (pred - y)
             pull /= np.sqrt(yerr ** 2 + pred_var + self.nugget ** 2)
             res = pred - y
             self._pull.append(pull)
             self.prediction.append(pred)
-            for t in range(n):
+            for t in range(len(y)):
                 self.pull.append(pull[t])
                 self.residual.append(res[t])
         self.pull_average, self.pull_std = normal.fit(self.pull)
 
-    def _loo_host_svd(self, sn, y, x, yerr, dd, substract_mean):
+    def _loo_batched(self, dev, dim, objs, substract_mean):
+        """Every (object, left-out point) pair is one sub-problem; returns [(pred, pred_var)] per object."""
+        use_mean = substract_mean or self.y_mean is not None
+        subs = {}                              # padded size -> list of (sn, t, x_keep, r_keep, d_keep)
+        offs = [np.zeros(len(o[0])) for o in objs]
+        for sn, (y, x, yerr, dd) in enumerate(objs):
+            n = len(y)
+            for t in range(n):
+                keep = np.ones(n, dtype=bool)
+                keep[t] = False
+                if use_mean:
+                    y0 = return_mean(y[keep], x[keep], mean_y=self.y_mean, mean_xaxis=self.x_axis_mean, diff=dd)
+                    offs[sn][t] = np.atleast_1d(return_mean(y[keep], x[keep], new_x=x, mean_y=self.y_mean,
+                                                            mean_xaxis=self.x_axis_mean, diff=dd) * np.ones(n))[t]
+                else:
+                    y0 = 0.
+                np_ = (max(n - 1, 1) + 127) // 128 * 128
+                subs.setdefault(np_, []).append((sn, t, x[keep], y[keep] - y0,
+                                                 _kernel.diag_term(n - 1, yerr[keep], 0., 0.)))
+        out = [(np.zeros(len(o[0])), np.zeros(len(o[0]))) for o in objs]
+        kp = _kparams(dim, self.hyperparameters, self.nugget)
+        kss_noise = 0. ** 2 + 0. ** 2 + self.nugget ** 2
+        for np_ in sorted(subs, reverse=True):
+            members = subs[np_]
+            per = max(1, int(gpm.BATCH_BYTES_LIMIT // ((np_ + 128) * np_ * 8)))
+            for lo in range(0, len(members), per):
+                part = members[lo:lo + per]
+                if any(len(p[3]) == 0 for p in part):
+                    raise np.linalg.LinAlgError('leave-one-out needs at least two points per object')
+                grids = np.stack([np.asarray(objs[p[0]][1][p[1]], dtype=np.float64).reshape((1,) + objs[p[0]][1].shape[1:])
+                                  for p in part])
+                _, info, mu, var = dev.batch_fit(dim, [p[2] for p in part], [p[3] for p in part], [p[4] for p in part],
+                                                 kp, xnew=grids, kss_noise=kss_noise, xnew_per_object=True)
+                if np.any(info):
+                    b = int(np.nonzero(info)[0][0])
+                    raise np.linalg.LinAlgError('leave-one-out matrix (object %d, point %d) is not positive definite'
+                                                % (part[b][0], part[b][1]))
+                for k, p in enumerate(part):
+                    out[p[0]][0][p[1]] = mu[k, 0] + offs[p[0]][p[1]]
+                    out[p[0]][1][p[1]] = abs(var[k, 0])
+        return out
+
+    def _loo_svd(self, sn, y, x, yerr, dd, substract_mean):
+        """The reference's own loop (pull.py:51-90) through the GP class with svd_method=True forced onto the
+        device eigensolver route (used for noise-free / non-positive-definite data)."""
         n = len(y)
         pred, pred_var = np.zeros(n), np.zeros(n)
-        for t in range(n):
-            keep = np.ones(n, dtype=bool)
-            keep[t] = False
-            gpp = gaussian_process(y[keep], x[keep], y_err=yerr[keep], Mean_Y=self.y_mean,
-                                   Time_mean=self.x_axis_mean, kernel=self.kernel,
-                                   diff=None if dd is None else [dd], substract_mean=substract_mean,
-                                   device=self._device)
-            gpp.hyperparameters = self.hyperparameters
-            gpp.nugget = self.nugget
-            gpp.get_prediction(new_binning=x, svd_method=True)
-            self.gpp = gpp
-            pred[t] = gpp.Prediction[0][t]
-            pred_var[t] = abs(gpp.covariance_matrix[0][t, t])
+        saved = gpm.SVD_VIA_CHOLESKY_WHEN_PD
+        try:
+            gpm.SVD_VIA_CHOLESKY_WHEN_PD = False
+            for t in range(n):
+                keep = np.ones(n, dtype=bool)
+                keep[t] = False
+                gpp = gaussian_process(y[keep], x[keep], y_err=yerr[keep], Mean_Y=self.y_mean,
+                                       Time_mean=self.x_axis_mean, kernel=self.kernel,
+                                       diff=None if dd is None else [dd], substract_mean=substract_mean,
+                                       device=self._device)
+                gpp.hyperparameters = self.hyperparameters
+                gpp.nugget = self.nugget
+                gpp.get_prediction(new_binning=x, svd_method=True)
+                self.gpp = gpp
+                pred[t] = gpp.Prediction[0][t]
+                pred_var[t] = abs(gpp.covariance_matrix[0][t, t])
+        finally:
+            gpm.SVD_VIA_CHOLESKY_WHEN_PD = saved
         return pred, pred_var
 
     def plot_result(self, binning=60):

@@ -775,3 +775,33 @@ def test_shared_then_own_grids_same_shape(cg):
         want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=None, svd_method=False, cov=False)
         for i in range(3):
             np.testing.assert_allclose(gp.Prediction[i], want['prediction'][i], rtol=0, atol=1e-10)
+
+
+def test_pull_many_objects_default_arguments(cg):
+    """build_pull over several objects of different sizes with the reference's default arguments
+    (svd_method=True): all leave-one-out sub-problems go down as bucketed batches (no per-point loop) and equal the
+    oracle's reference loop; noise-free data take the eigensolver route and still give finite pulls."""
+    rng = np.random.default_rng(31)
+    sizes = [12, 35, 150, 20, 131]
+    xs = [np.sort(rng.uniform(0., 0.5 * n + 5., n)) for n in sizes]
+    es = [rng.uniform(0.05, 0.2, n) for n in sizes]
+    ys = [np.sin(x / 3.) + e * rng.standard_normal(len(x)) for x, e in zip(xs, es)]
+    hyp = [0.9, 2.5]
+    dev = cg._lib.Device()
+    calls = []
+    real = dev.batch_fit
+    dev.batch_fit = lambda *a, **k: (calls.append(len(a[1])), real(*a, **k))[1]
+    bp = cg.build_pull(ys, xs, hyp, nugget=0.03, y_err=es, device=dev)
+    bp.compute_pull()                                            # svd_method=True, substract_mean=False
+    assert sorted(calls) == sorted([12 + 35 + 20, 150 + 131])    # two buckets (Np = 128, 256), every sub-problem once
+    want_pull, want_res, _ = orc.compute_pull(ys, xs, hyp, nugget=0.03, y_err=es, svd_method=True)
+    np.testing.assert_allclose(bp.pull, want_pull, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(bp.residual, want_res, rtol=0, atol=1e-8)
+    bm = cg.build_pull(ys[:2], xs[:2], hyp, nugget=0.03, y_err=es[:2], device=dev)
+    bm.compute_pull(substract_mean=True)
+    want_pull, _, _ = orc.compute_pull(ys[:2], xs[:2], hyp, nugget=0.03, y_err=es[:2], svd_method=True, substract_mean=True)
+    np.testing.assert_allclose(bm.pull, want_pull, rtol=0, atol=1e-7)
+    x0 = np.linspace(0., 4., 12)
+    b0 = cg.build_pull([np.sin(x0)], [x0], [1., 1.], device=dev)          # no y_err, no nugget: singular sub-matrices
+    b0.compute_pull()
+    assert len(b0.pull) == 12 and np.all(np.isfinite(b0.residual))
