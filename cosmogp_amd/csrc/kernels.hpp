@@ -658,6 +658,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.;
+    // acc[i][j] at lane l = C[16 i + 4 blk + (l >> 4)][4 j + (l & 3)],  blk = (l >> 2) & 3
+    double* Cg = C + (long)(ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq) * ldc + tj * TN + wn * (TN / WN) + lp;
+    // Small wave tiles (the thin updates): the C values are fetched BEFORE the K loop, so the read-modify-write
+    // latency of the epilogue hides under it (8 more registers; the large form keeps its 4 waves per SIMD instead)
+    constexpr bool EARLYC = (MT * NJ <= 8);
+    double cv[EARLYC ? MT : 1][EARLYC ? NJ : 1];
+    if (EARLYC && beta != 0.) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cv[EARLYC ? i : 0][EARLYC ? j : 0] = Cg[(long)(i * 16) * ldc + j * 4];
+    }
 
     // Global -> registers two stages ahead, registers -> LDS one stage ahead: a load has two
     // full stages of MFMA work to land (thin K = 128 updates are otherwise latency-bound).
@@ -732,9 +744,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
         __syncthreads();
     }
 
-    // acc[i][j] at lane l = C[16 i + 4 blk + (l >> 4)][4 j + (l & 3)],  blk = (l >> 2) & 3
-    double* Cg = C + (long)(ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq) * ldc + tj * TN + wn * (TN / WN) + lp;
-    if (beta != 0.) {
+    if (EARLYC && beta != 0.) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                Cg[(long)(i * 16) * ldc + j * 4] = alpha * acc[i][j] + beta * cv[EARLYC ? i : 0][EARLYC ? j : 0];
+    } else if (beta != 0.) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
