@@ -805,3 +805,49 @@ def test_pull_many_objects_default_arguments(cg):
     b0 = cg.build_pull([np.sin(x0)], [x0], [1., 1.], device=dev)          # no y_err, no nugget: singular sub-matrices
     b0.compute_pull()
     assert len(b0.pull) == 12 and np.all(np.isfinite(b0.residual))
+
+
+def test_abi_status_codes(cg):
+    """Raw C-ABI calls: call-order and argument errors come back as negative status codes with a message (no
+    crash, no silent success); a non-positive-definite matrix as the positive LAPACK-style info."""
+    import ctypes
+    from cosmogp_amd import _lib
+    lib = _lib.load_library()
+    dp = ctypes.POINTER(ctypes.c_double)
+    h = ctypes.c_void_p()
+    assert lib.cgp_create(0, ctypes.byref(h)) == 0
+    try:
+        kp = (ctypes.c_double * 7)(1., 1., 4., 0., 0., 0., 0.)
+        ll = ctypes.c_double()
+        # nothing uploaded yet
+        assert lib.cgp_fit(h, kp, None, None, 0, None, 0., ctypes.byref(ll), None, None, None) == -3
+        assert b'no data' in lib.cgp_last_error(h)
+        five = (ctypes.c_double * 5)()
+        assert lib.cgp_fit_grad(h, kp, None, ctypes.byref(ll), None, five) == -3
+        assert lib.cgp_sweep_loglik(h, 1, kp, None, ctypes.byref(ll), None) == -3
+        assert lib.cgp_batch_fit_grad(h, kp, ctypes.byref(ll), None, five) == -3
+        assert lib.cgp_fit_predict(h, kp, 1, None, 0., five, None, None) == -3          # no factor
+        assert lib.cgp_bench_fit_objects(h, 1, 1, ctypes.byref(ll)) == -3
+        # bad arguments
+        x = (ctypes.c_double * 4)(0., 1., 2., 3.)
+        assert lib.cgp_fit_set_data(h, 3, x, x, 4) == -1
+        assert lib.cgp_fit_set_data(h, 1, x, x, 0) == -1
+        assert lib.cgp_rbf(h, 1, x, 4, None, 0, kp, None, None, 4) == -1
+        assert lib.cgp_fit_set_data(h, 1, x, x, 4) == 0
+        assert lib.cgp_sweep_loglik(h, 0, kp, None, ctypes.byref(ll), None) == -1
+        assert lib.cgp_sweep_loglik(h, 257, kp, None, ctypes.byref(ll), None) == -1
+        assert lib.cgp_fit(h, None, None, None, 0, None, 0., ctypes.byref(ll), None, None, None) == -1
+        # a valid call still works on the same handle afterwards ...
+        diag = (ctypes.c_double * 4)(0.1, 0.1, 0.1, 0.1)
+        assert lib.cgp_fit(h, kp, diag, None, 0, None, 0., ctypes.byref(ll), None, None, None) == 0
+        ref = orc.log_likelihood_gp(np.array([0., 1., 2., 3.]), np.array([0., 1., 2., 3.]), 'RBF1D', [1., 2.], 0.,
+                                    y_err=np.sqrt(np.full(4, 0.1)), svd_method=False)[0]
+        assert abs(ll.value - ref) <= 1e-12 * abs(ref)
+        # ... and a matrix that is not positive definite reports the failing leading minor
+        K = np.eye(5)
+        K[3, 3] = -2.
+        inv = np.empty((5, 5))
+        assert lib.cgp_cholesky_inverse(h, K.ctypes.data_as(dp), 5, 5, inv.ctypes.data_as(dp), None) == 4
+    finally:
+        assert lib.cgp_destroy(h) == 0
+    assert lib.cgp_destroy(None) == -1 and lib.cgp_synchronize(None) == -1
