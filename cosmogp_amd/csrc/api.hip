@@ -276,9 +276,11 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const long nr = rows / 64, nc = cols / 64;
         const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
         if (tiles <= 0) return 0;
+        {
         dim3 g((unsigned)tiles, 1, (unsigned)B);
         hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;

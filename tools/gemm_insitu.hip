@@ -595,6 +595,166 @@ static std::vector<int2> build_tab(int nr, int nc, int tri, int RT) {
     return tab;
 }
 
+// (developer experiment, not in the product header: measured equal to the standard forms, the shallow updates are HBM-bound)
+// ------------------------------------------------------------------------------------
+// K5-flat: the same update for SHALLOW depths (K <= 512: the depth-128 / 256 / 512 updates of the recursion), where a
+// tile lasts only 8-32 stages and k_gemm_nt's per-tile prologue (two global round trips before the first MFMA)
+// and epilogue are a large share of it.  Persistent workgroups walk their tiles as ONE flat stream of stages:
+// the two-stages-ahead prefetch runs across tile boundaries (the first stages of the next tile load under the last
+// MFMAs of the current one), and the C values of the next tile are fetched when its first stage is issued.  Batched
+// problems are folded into the tile id (no blockIdx.z).  Tile maps, stage order and accumulation order per C
+// element are those of k_gemm_nt<TM, TN, WM, WN, 16>: bit-identical results.
+// ------------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_flat(
+    double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
+    long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int nbatch) {
+    constexpr int KB = 16, NTH = 64 * WM * WN;
+    constexpr int MT = TM / WM / 16, NJ = TN / WN / 4;
+    constexpr int KS = KB + 2, CPR = KB / 2;
+    constexpr int PA = TM * CPR / NTH, PB = TN * CPR / NTH, RSTEP = NTH / CPR;
+    static_assert(PA >= 1 && PB >= 1 && MT * NJ <= 8, "small wave tiles only");
+    constexpr int RT = TM / TN;
+    static_assert(TM == RT * TN && (RT == 1 || RT == 2), "tile shape");
+    __shared__ __attribute__((aligned(16))) double As[2][TM * KS];
+    __shared__ __attribute__((aligned(16))) double Bs[2][TN * KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4, lp = lane & 3;
+    const int srow = tid / CPR, sch = (tid % CPR) * 2;
+    const int nt = nc / RT;
+    const int ntri = tri ? RT * nt * (nt + 1) / 2 : 0;
+    const int ntot = ntri + (nr - (tri ? nt : 0)) * nc;          // tiles per problem
+    const long total = (long)ntot * nbatch;                      // tiles of the launch
+    const int nk = K / KB;                                       // even (K is a multiple of 32)
+    // my tiles: blockIdx.x, blockIdx.x + gridDim.x, ...
+    const long first = blockIdx.x;
+    if (first >= total) return;
+    const int ntiles = (int)((total - first + gridDim.x - 1) / gridDim.x);
+    const int nstage = ntiles * nk;
+
+    struct Tile { const double* a; const double* b; double* c; };
+    auto locate = [&](int it) {
+        const long id = first + (long)it * gridDim.x;
+        const int z = (int)(id / ntot), bid = (int)(id - (long)z * ntot);
+        int ti, tj;
+        if (bid < ntri) {
+            int i = (int)((sqrtf(8.f * bid / RT + 1.f) - 1.f) * 0.5f);
+            while (RT * (i + 1) * (i + 2) / 2 <= bid) ++i;
+            while (RT * i * (i + 1) / 2 > bid) --i;
+            ti = i;
+            tj = bid - RT * i * (i + 1) / 2;
+        } else {
+            const int r = bid - ntri;
+            ti = (tri ? nt : 0) + r / nc;
+            tj = r % nc;
+        }
+        Tile t;
+        t.a = A + (long)z * sAB + (long)(ti * TM + srow) * ld + sch;
+        t.b = B + (long)z * sAB + (long)(tj * TN + srow) * ld + sch;
+        t.c = C + (long)z * sC + (long)(ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq) * ldc + tj * TN +
+              wn * (TN / WN) + lp;
+        return t;
+    };
+
+    d2 ra[2][PA], rb[2][PB];
+    double acc[MT][NJ], cv[MT][NJ], cvn[MT][NJ];
+    // load stream: stage index sl = (tile il, depth step kl)
+    Tile tl = locate(0), tc = tl;
+    int kl = 0, il = 0;
+    auto gload = [&](auto par) {           // fetch the load stream's current stage, then advance it (clamped at the end)
+        constexpr int P = decltype(par)::value;
+        const int k1 = kl * KB;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[P][p] = *(const d2*)(tl.a + (long)(RSTEP * p) * ld + k1);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[P][p] = *(const d2*)(tl.b + (long)(RSTEP * p) * ld + k1);
+        if (kl == 0 && beta != 0.) {       // first stage of a tile: its C values ride along
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cvn[i][j] = tl.c[(long)(i * 16) * ldc + j * 4];
+        }
+        if (++kl == nk) {
+            if (il + 1 < ntiles) { ++il; kl = 0; tl = locate(il); }
+            else kl = nk - 1;              // past the end: re-load the last stage (never stored)
+        }
+    };
+    auto lstore = [&](auto par, int buf) {
+        constexpr int P = decltype(par)::value;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *(d2*)(&As[buf][(srow + RSTEP * p) * KS + sch]) = ra[P][p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *(d2*)(&Bs[buf][(srow + RSTEP * p) * KS + sch]) = rb[P][p];
+    };
+    auto compute = [&](int cur) {
+        d2 fa[MT], fb[NJ];
+#pragma unroll
+        for (int t = 0; t < KB / 8; ++t) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *(const d2*)(&As[cur][(wm * (TM / WM) + i * 16 + lr) * KS + 8 * t + 2 * lq]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                fb[j] = *(const d2*)(&Bs[cur][(wn * (TN / WN) + j * 4 + lp) * KS + 8 * t + 2 * lq]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].x, fb[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].y, fb[j].y, acc[i][j]);
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { acc[i][j] = 0.; cv[i][j] = 0.; cvn[i][j] = 0.; }
+    gload(P0{});                            // stage 0 (+ C of tile 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cv[i][j] = cvn[i][j];
+    gload(P1{});                            // stage 1
+    lstore(P0{}, 0);
+    __syncthreads();
+    int kc = 0, ic = 0;                     // compute stream
+    for (int s = 0; s < nstage; s += 2) {
+        gload(P0{});                        // stage s + 2
+        compute(0);
+        lstore(P1{}, 1);
+        __syncthreads();
+        gload(P1{});                        // stage s + 3
+        compute(1);
+        kc += 2;
+        if (kc == nk) {                     // tile finished: write it, take over the C values fetched for the next one
+            if (beta != 0.) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) tc.c[(long)(i * 16) * ldc + j * 4] = alpha * acc[i][j] + beta * cv[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) tc.c[(long)(i * 16) * ldc + j * 4] = alpha * acc[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { acc[i][j] = 0.; cv[i][j] = cvn[i][j]; }
+            kc = 0;
+            if (++ic < ntiles) tc = locate(ic);
+        }
+        lstore(P0{}, 0);
+        __syncthreads();
+    }
+}
+
+
 struct Upd { long a, c0, rows, cols, K; };
 static void plan(long c0, long c1, long R, std::vector<Upd>& out) {
     if (c1 - c0 <= 128) return;
