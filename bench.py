@@ -392,6 +392,12 @@ def main():
                      assemble_K_GBs=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9, 1),
                      assemble_K_frac_of_hbm=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9 / SPEC_HBM_GBS, 4))
     if rank == 0:
+        if extra.get('assemble_K_GBs'):
+            # second roofline object: the covariance build (K1), HBM-write bound by its algorithmic bytes
+            # (lower triangle of K, 8 N (N + 1) / 2 B), measured with HIP events on one fit at a time
+            extra['roofline_assembly'] = dict(bound='hbm', achieved=extra['assemble_K_GBs'], peak=SPEC_HBM_GBS, unit='GB/s',
+                                              frac=extra['assemble_K_frac_of_hbm'], kernel='k_assemble_train',
+                                              note='also bounded by fp64 VALU issue (~60 instructions per element), DESIGN.md 4.2')
         if not args.no_extras:
             mfma_tf, hbm_gbs = dev.microbench()
             extra.update(measured_mfma_f64_ceiling_tflops=round(mfma_tf, 2), measured_hbm_write_gbs=round(hbm_gbs, 1))
