@@ -115,6 +115,22 @@ __global__ __launch_bounds__(256) void k_assemble_train(
         ux0 = t0.x; uy0 = t0.y; ux1 = t1.x; uy1 = t1.y;
     }
     __syncthreads();
+    if (row0 + 63 < n && col0 + 127 < n && (col0 + 127 < row0 || col0 > row0 + 63)) {
+        // interior tile (no diagonal element, no padding): no selects
+#pragma unroll 4
+        for (int rr = wave; rr < 64; rr += 4) {
+            const int i = row0 + rr;
+            const double vx = rx[rr * DIM], vy = (DIM == 2) ? rx[rr * DIM + 1] : 0.;
+            d2 o;
+            {
+#pragma clang fp contract(off)
+                o.x = kp.amp_train * exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp));
+                o.y = kp.amp_train * exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp));
+            }
+            *(d2*)(M + (long)i * ld + c) = o;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int rr = wave; rr < 64; rr += 4) {
         const int i = row0 + rr;
