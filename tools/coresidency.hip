@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         // beside the bulk GEMM (4096 x 4096 x 4096, 128x128 tiles, 8 waves): ~2.5 ms
         const int rows = tdim, cols = tdim, K = 4096, nr = rows / 128, nc = cols / 128;
         hipEventRecord(g0, sb);
-        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, 16, 0>), dim3(nr * nc), dim3(512), 0, sb, M + K, ld, 0L, M, M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0);
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, 16, 0>), dim3(nr * nc), dim3(512), 0, sb, M + K, ld, 0L, M, M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0, 0);
         hipEventRecord(g1, sb);
         hipEventRecord(e0, sa);
         for (int i = 0; i < nchain; ++i) hipLaunchKernelGGL(chainlike, dim3(1), dim3(256), lds_small[which], sa, out, iters);
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
         float beside, gemm; hipEventElapsedTime(&beside, e0, e1); hipEventElapsedTime(&gemm, g0, g1);
         // gemm alone
         hipEventRecord(g0, sb);
-        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, 16, 0>), dim3(nr * nc), dim3(512), 0, sb, M + K, ld, 0L, M, M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0);
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 4, 16, 0>), dim3(nr * nc), dim3(512), 0, sb, M + K, ld, 0L, M, M, ld, 0L, K, nr, nc, 0, -1.0, 1.0, 0, 0);
         hipEventRecord(g1, sb); hipEventSynchronize(g1);
         float galone; hipEventElapsedTime(&galone, g0, g1);
         printf("small kernel LDS %3d KB: %d launches alone %.1f us each; beside bulk GEMM %.1f us each; GEMM %.2f ms (alone %.2f ms)\n",
