@@ -12,9 +12,12 @@ Workloads (seeds fixed):
   c3 (default at N=1)  2D RBF GP, N=8192, M=2500, single fit     -- the size BASELINE.json's metric names
   c2                   1D RBF GP, N=4096, M=1024, single fit
   c4                   1D light curves, N=512, M=19, 128 fits per GPU per step (1024 on 8 GPUs)
-N > 1: one process per GPU (torch.distributed.run), every rank fits its own objects (weak
-scaling, no data-path collective); RCCL is used for the barrier, the max-over-ranks of the timing
-and one all_gather of the predictions per step batch.
+N > 1: one process per GPU, every rank fits its own objects (weak scaling, no data-path collective);
+RCCL -- called directly inside libcosmogp_hip (cgp_comm_*), no PyTorch -- does the barrier, the
+max-over-ranks of the timing and the ONE all-gather of the predictions.  `python bench.py --gpus N` run
+plainly starts its N ranks itself (child processes, spawned before the parent touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's RANK / LOCAL_RANK /
+WORLD_SIZE are used as they are.
 
 Rank 0 prints ONE JSON line.  roofline = the dominant kernel (k_gemm_nt, fp64 MFMA): algorithmic
 flops per launch / average launch duration measured with HIP events on the kernel's own stream.
@@ -46,7 +49,7 @@ def make_workload(name, rank=0, obj=0):
         y = np.sin(X[:, 0] / 150.) * np.cos(X[:, 1] / 170.) + 0.1 * rng.standard_normal(n)
         hyp = [1., 110., 110., 0.]
         return dict(dim=2, n=n, m=m, x=X, y=y, e=np.full(n, 0.1), xnew=Xn, hyp=hyp,
-                    kp=K.kernel_params_2d(hyp), label='2D RBF GP N=8192 M=2500 single fit (BASELINE config[2])')
+                    kp=K.kernel_params_2d(hyp), label='2D RBF GP N=8192 M=2500 (BASELINE config[2])')
     if name == 'c2':
         rng = np.random.default_rng(2 + 1000 * rank + 37 * obj)
         n, m = 4096, 1024
@@ -55,7 +58,7 @@ def make_workload(name, rank=0, obj=0):
         hyp = [1., 2.]
         return dict(dim=1, n=n, m=m, x=x, y=y, e=np.full(n, 0.1),
                     xnew=np.random.default_rng(20 + 1000 * rank).uniform(0., 400., m), hyp=hyp,
-                    kp=K.kernel_params_1d(hyp), label='1D RBF GP N=4096 M=1024 single fit (BASELINE config[1])')
+                    kp=K.kernel_params_1d(hyp), label='1D RBF GP N=4096 M=1024 (BASELINE config[1])')
     if name == 'c4':
         B, n, m = 128, 512, 19
         xs, ys, es = [], [], []
@@ -87,63 +90,204 @@ def make_workload(name, rank=0, obj=0):
     raise SystemExit('unknown workload %r' % name)
 
 
-def cpu_baseline(wl):
-    """The oracle timed on the host cores on a bounded sample of the same workload."""
-    from oracle import cosmogp_oracle as orc
+def _cpu_info():
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    blas, threads = 'unknown', os.cpu_count()
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        infos = [p for p in threadpool_info() if p.get('user_api') == 'blas']
+        if infos:
+            blas = ', '.join(sorted(set('%s %s (%s)' % (p.get('internal_api'), p.get('version'), p.get('threading_layer', p.get('architecture', '')))
+                                        for p in infos)))
+            threads = max(p.get('num_threads', 1) for p in infos)
     except Exception:
-        threads = os.cpu_count()
-    t0 = time.perf_counter()
+        pass
+    return dict(cpu_model=model, physical_cores=int(phys), logical_cpus=int(os.cpu_count()), blas=blas), int(threads)
+
+
+def _best_of(fn, max_reps=5, budget_s=8.0):
+    """best wall time of up to max_reps runs of fn(), stopping once budget_s is spent (at least one run)."""
+    best, spent, reps = np.inf, 0., 0
+    while reps < max_reps and (reps == 0 or spent < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        best, spent, reps = min(best, dt), spent + dt, reps + 1
+    return best, reps
+
+
+def _c4_pool_fit(args):
+    """one N=512 light-curve fit on ONE BLAS thread (worker of the process pool)"""
+    from oracle import cosmogp_oracle as orc
+    x, y, e, hyp, xnew = args
+    Kc = orc.rbf_kernel_1d(x, hyp, y_err=e)
+    H = orc.rbf_kernel_1d(x, hyp, new_x=xnew)
+    mu, var, ll = orc.fit_predict_cho(Kc, y, H, np.full(len(xnew), hyp[0] ** 2))
+    return float(ll)
+
+
+def cpu_baseline(wl):
+    """The oracle (NumPy/SciPy restatement of the reference) timed on the host cores, on a bounded sample of the
+    same workload: warm-up, best of up to 5, all BLAS threads and ONE thread, BLAS vendor and
+    CPU model reported; the batch workload also through a process pool (one fit per worker, one thread each)."""
+    from oracle import cosmogp_oracle as orc
+    from scipy import linalg as la
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    info, threads = _cpu_info()
+    t_start = time.perf_counter()
+
+    def one_thread(fn):
+        if threadpool_limits is None:
+            return None
+        with threadpool_limits(limits=1, user_api='blas'):
+            return _best_of(fn, 3, 4.0)
+
     if 'B' in wl:
         nfit = 4
-        for b in range(nfit):
-            Kc = orc.rbf_kernel_1d(wl['xs'][b], wl['hyp'], y_err=wl['es'][b])
-            H = orc.rbf_kernel_1d(wl['xs'][b], wl['hyp'], new_x=wl['xnew'])
-            orc.fit_predict_cho(Kc, wl['ys'][b], H, np.full(wl['m'], wl['hyp'][0] ** 2))
-        sample = '%d of the %d fits of one step (N=512, M=19), cho_factor/cho_solve form' % (nfit, wl['B'])
-    elif 'sweep' in wl:
-        # bounded sample: ONE log-likelihood of the sweep at a quarter of the points (N = 4096 of 16384),
-        # scaled by the N^3 law to the full size; the full-size CPU factorisation alone takes minutes
-        from scipy import linalg as la
-        nfit = 1
-        ns_ = wl['n'] // 4
-        Kc = orc.rbf_kernel_2d(wl['x'][:ns_], wl['hyp'], y_err=wl['e'][:ns_], sigma2_in_train=True)
-        c = la.cho_factor(Kc, lower=True)
-        la.cho_solve(c, wl['y'][:ns_])
-        dt_small = time.perf_counter() - t0
-        scale = (wl['n'] / float(ns_)) ** 3
-        return dict(value=1.0 / (dt_small * scale), unit='fits/s', cores=int(threads), kind='port',
-                    sample='1 log-likelihood at N=%d (%.2f s) scaled by (N/n)^3 = %.0f to N=%d' %
-                           (ns_, dt_small, scale, wl['n']), seconds=round(dt_small, 3))
-    else:
-        nfit = 1
-        kern = orc.rbf_kernel_1d if wl['dim'] == 1 else orc.rbf_kernel_2d
-        Kc = kern(wl['x'], wl['hyp'], y_err=wl['e'])
-        H = kern(wl['x'], wl['hyp'], new_x=wl['xnew'])
+        args = [(wl['xs'][b], wl['ys'][b], wl['es'][b], wl['hyp'], wl['xnew']) for b in range(wl['B'])]
+
+        def serial():
+            for b in range(nfit):
+                _c4_pool_fit(args[b])
+        serial()                                                   # warm-up
+        best, reps = _best_of(serial, 5, 6.0)
+        one = one_thread(serial)
+        out = dict(value=nfit / best, unit='fits/s', cores=threads, kind='port',
+                   sample='%d of the %d fits of one step (N=512, M=19), cho_factor/cho_solve form, one after the other; '
+                          'best of %d after a warm-up' % (nfit, wl['B'], reps), seconds=round(best, 4))
+        if one:
+            out['one_thread'] = dict(value=nfit / one[0], unit='fits/s', cores=1, seconds=round(one[0], 4))
+        # the fair CPU form of embarrassingly parallel fits: a process pool, one fit per worker, one BLAS thread each
+        try:
+            import multiprocessing as mp
+            nw = min(info['physical_cores'], wl['B'])
+            env_keep = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS')}
+            os.environ.update(OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+            with mp.get_context('spawn').Pool(nw) as pool:
+                # (time-outs: a pool whose workers cannot start would respawn them forever)
+                pool.map_async(_c4_pool_fit, args[:nw]).get(timeout=120)          # warm-up (imports, first touch)
+                t0 = time.perf_counter()
+                pool.map_async(_c4_pool_fit, args, chunksize=max(1, len(args) // (4 * nw))).get(timeout=120)
+                dtp = time.perf_counter() - t0
+            for k, v in env_keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            out['process_pool'] = dict(value=len(args) / dtp, unit='fits/s', workers=nw, threads_per_worker=1,
+                                       sample='all %d fits of one step' % len(args), seconds=round(dtp, 3))
+        except Exception as exc:                                   # a box without fork/spawn rights: report, do not die
+            out['process_pool'] = dict(error=repr(exc))
+        out.update(info)
+        out['baseline_seconds_total'] = round(time.perf_counter() - t_start, 2)
+        return out
+
+    kern = orc.rbf_kernel_1d if wl['dim'] == 1 else orc.rbf_kernel_2d
+    sweep = 'sweep' in wl
+    n = wl['n']
+    # bounded: the full-size CPU factorisation of C5 alone takes minutes -> a quarter of the points, N^3 law;
+    # C2 / C3 run at full size with all threads
+    ns_ = n // 4 if sweep else n
+    scale = (n / float(ns_)) ** 3
+    xs_, ys_, es_ = wl['x'][:ns_], wl['y'][:ns_], wl['e'][:ns_]
+    kw = dict(sigma2_in_train=True) if sweep else {}
+    stage, last = {}, {}
+
+    def full_fit(x_=xs_, y_=ys_, e_=es_, record=True):
+        t0 = time.perf_counter()
+        Kc = kern(x_, wl['hyp'], y_err=e_, **kw)
+        H = None if sweep else kern(x_, wl['hyp'], new_x=wl['xnew'])
         t1 = time.perf_counter()
-        orc.fit_predict_cho(Kc, wl['y'], H, np.full(wl['m'], 1.0))
+        if sweep:
+            c = la.cho_factor(Kc, lower=True)
+            la.cho_solve(c, y_)
+        else:
+            orc.fit_predict_cho(Kc, y_, H, np.full(wl['m'], 1.0))
         t2 = time.perf_counter()
-        sample = ('1 full fit of the workload (assembly %.2f s + cho_factor/cho_solve/predict %.2f s)'
-                  % (t1 - t0, t2 - t1))
-        # the reference's own algorithm (inv_matrix.py:23-25 explicit inverse, then dots) on the same matrices
+        if record and (not stage or t2 - t0 < stage['total']):
+            stage.update(assembly=t1 - t0, factor_solve=t2 - t1, total=t2 - t0)
+        last.update(assembly=t1 - t0, factor_solve=t2 - t1)
+
+    nw_ = max(256, ns_ // 8)
+    full_fit(xs_[:nw_], ys_[:nw_], es_[:nw_], record=False)        # warm-up (BLAS threads, page faults) at N/8
+    best, reps = _best_of(full_fit, 5, 10.0)
+    # a reduced sample is scaled stage by stage: assembly ~ N^2, factor / solve ~ N^3
+    est = stage['assembly'] * (n / float(ns_)) ** 2 + stage['factor_solve'] * scale
+    out = dict(value=1.0 / est, unit='fits/s', cores=threads, kind='port', seconds=round(best, 3),
+               sample=('%s at N=%d%s: assembly %.2f s + cho_factor/cho_solve%s %.2f s; best of %d after a warm-up'
+                       % ('1 log-likelihood' if sweep else '1 full fit of the workload', ns_,
+                          (' scaled to N=%d (assembly x %.0f, factorisation x %.0f)' % (n, (n / float(ns_)) ** 2, scale))
+                          if scale > 1 else '', stage['assembly'], '' if sweep else '/predict', stage['factor_solve'], reps)))
+    # ONE BLAS thread: at a quarter of the size (the full size would take minutes), scaled by the N^3 law
+    n1 = max(512, ns_ // 4)
+    one = one_thread(lambda: full_fit(xs_[:n1], ys_[:n1], es_[:n1], record=False))
+    if one:
+        est1 = last['assembly'] * (n / float(n1)) ** 2 + last['factor_solve'] * (n / float(n1)) ** 3
+        out['one_thread'] = dict(value=1.0 / est1, unit='fits/s', cores=1,
+                                 sample='the same at N=%d (assembly %.2f s + factorisation %.2f s) scaled to N=%d '
+                                        '(assembly x %.0f, factorisation x %.0f)'
+                                        % (n1, last['assembly'], last['factor_solve'], n, (n / float(n1)) ** 2,
+                                           (n / float(n1)) ** 3))
+    if not sweep:
+        # the reference's own algorithm (inv_matrix.py:23-25 explicit inverse, then dots) at half the size
+        # (it takes ~3x the cho form), scaled by the N^3 law
+        nr = n // 2
+        t0 = time.perf_counter()
+        Kc = kern(wl['x'][:nr], wl['hyp'], y_err=wl['e'][:nr])
+        H = kern(wl['x'][:nr], wl['hyp'], new_x=wl['xnew'])
+        t1 = time.perf_counter()
         inv = orc.cholesky_inverse(Kc)
-        mu_ref = H @ (inv @ wl['y'])
+        mu_ref = H @ (inv @ wl['y'][:nr])
         var_ref = 1.0 - np.einsum('ij,ij->i', H @ inv, H)
-        t3 = time.perf_counter()
-        dt = t2 - t0
-        return dict(value=nfit / dt, unit='fits/s', cores=int(threads), kind='port', sample=sample,
-                    seconds=round(dt, 3),
-                    reference_form=dict(value=1.0 / ((t1 - t0) + (t3 - t2)), unit='fits/s',
-                                        note='same assembly + explicit inverse (cholesky, inv(L), inv_L.T @ inv_L) '
-                                             'and dot products like cosmogp/inv_matrix.py:23-25, '
-                                             'Gaussian_process.py:334-361 (variance diagonal only)',
-                                        seconds=round((t1 - t0) + (t3 - t2), 3),
-                                        checksum=float(mu_ref[0] + var_ref[0])))
-    dt = time.perf_counter() - t0
-    return dict(value=nfit / dt, unit='fits/s', cores=int(threads), kind='port', sample=sample,
-                seconds=round(dt, 3))
+        dtr = time.perf_counter() - t0
+        out['reference_form'] = dict(value=1.0 / ((t1 - t0) * 4.0 + (dtr - (t1 - t0)) * 8.0), unit='fits/s',
+                                     seconds=round(dtr, 3),
+                                     note='assembly + explicit inverse (cholesky, inv(L), inv_L.T @ inv_L) and dot '
+                                          'products like cosmogp/inv_matrix.py:23-25, Gaussian_process.py:334-361 '
+                                          '(variance diagonal only) at N=%d, scaled to N=%d (assembly x 4, the rest x 8)' % (nr, n),
+                                     checksum=float(mu_ref[0] + var_ref[0]))
+    out.update(info)
+    out['baseline_seconds_total'] = round(time.perf_counter() - t_start, 2)
+    return out
+
+
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` run plainly: start N ranks (one per GPU) as child processes BEFORE anything in
+    this process touches the GPU, pass rank 0's JSON line through, return the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), CGP_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p_ in procs[1:]:
+        rc = max(rc, abs(p_.wait()))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -169,25 +313,25 @@ def main():
                          '4 for c4 (232k -> 290k fits/s), 1 for the lock-step sweep')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # not under a launcher: this process only starts the ranks (it never initialises HIP)
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world > 1 or 'RANK' in os.environ:          # launched by torch.distributed.run (any world size)
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl')
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
-        print('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world),
-              file=sys.stderr)
+        print('note: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
 
     import threading
     from cosmogp_amd import _lib
     from cosmogp_amd import kernel as K
     dev = _lib.Device(local_rank)
     dev.selftest_mfma()
+    comm = None
+    if world > 1 or 'RANK' in os.environ:          # launched as a rank (any world size): RCCL inside the library
+        from cosmogp_amd import multigpu
+        comm = multigpu.Comm(dev, rank=rank, world=world)
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
     if batched:
@@ -251,11 +395,8 @@ def main():
     def sync_all():
         for d in set([dev] + extra_devs + (fit_devs if (lock > 1 and 'sweep' not in wl) else [])):
             d._lib.cgp_synchronize(d._h)
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()                 # ncclAllReduce on dev's stream + stream synchronise
 
     all_devs = fit_devs if (lock > 1 and 'sweep' not in wl) else [dev] + extra_devs
 
@@ -313,18 +454,13 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps)
-    if dist is not None:                           # the one gather of the path: predictions of every rank
-        import torch
-        send = torch.from_numpy(np.ascontiguousarray(np.stack([np.ravel(mu), np.ravel(var)]))).cuda()
-        recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(recv.view(-1, *send.shape[1:]), send)
+    if comm is not None:                           # the one gather of the path: predictions of every rank
+        gathered = comm._allgather(np.stack([np.ravel(mu), np.ravel(var)]))
+        assert gathered.shape[0] == world
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
 
     # ---- roofline of the dominant kernel (event-instrumented pass, rank 0's GPU) --------------
     roof, extra = None, {}
@@ -336,10 +472,13 @@ def main():
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
         ach = flops / (gemm_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_%s.json' % args.workload)
-        if os.path.exists(tpath):          # HBM bytes per launch from the separate rocprofv3 --pmc passes
-            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+        traffic, tsrc = None, None
+        for rnd in ('r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
+            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.workload))
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+                tsrc = os.path.relpath(tpath, ROOT)
+                break
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms', launches_per_fit=int(launches),
@@ -359,8 +498,9 @@ def main():
             roof['launches_per_pass'] = roof.pop('launches_per_fit')
         roof['objects_per_launch'] = wl['B'] if batched else lock
         if traffic is not None:
-            roof['traffic_note'] = ('PMC FETCH_SIZE (x2, gfx950 wide-load correction) + WRITE_SIZE per launch, '
-                                    'separate rocprofv3 passes, see profiles/')
+            roof['traffic_source'] = ('replayed constant, not measured by this run: %s (PMC FETCH_SIZE x2, gfx950 '
+                                      'wide-load correction, + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of '
+                                      '`bench.py --no-extras`)' % tsrc)
     if not batched and not args.no_extras:
         if 'sweep' in wl:
             dev.fit(kps[0], None)                    # back to one candidate at a time on this handle
@@ -391,6 +531,53 @@ def main():
                      cholesky_gflops_equiv=round(sweep_flops / (potrf_ms * 1e-3) / 1e9, 1),
                      assemble_K_GBs=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9, 1),
                      assemble_K_frac_of_hbm=round(8. * n * (n + 1) / 2 / (st[0] * 1e-3) / 1e9 / SPEC_HBM_GBS, 4))
+    if not batched and not args.no_extras and roof is not None and 'single_fit_cholesky_gflops' in extra:
+        # the two numbers BASELINE.json's metric names for ONE fit at a time, next to the dominant-kernel roofline
+        roof['single_fit'] = dict(latency_ms=extra['single_fit_latency_ms'],
+                                  fits_per_sec=round(1e3 / extra['single_fit_latency_ms'], 2),
+                                  cholesky_ms=extra['single_fit_cholesky_ms'],
+                                  cholesky_gflops=extra['single_fit_cholesky_gflops'],
+                                  frac=round(extra['single_fit_cholesky_gflops'] / 1e3 / SPEC_FP64_MFMA_TFLOPS, 4),
+                                  note='one fit at a time on one handle (no lock-step batch, no second stream): full fit '
+                                       'latency, and N^3/3 flops over the wall time of a log-likelihood-only fit '
+                                       '(assembly + blocked Cholesky with one residual row)')
+    if not args.no_extras and 'sweep' not in wl:
+        # API-level rate, the SURVEY.md 8(d) definition of a fit: host arrays in -> device -> mu / var / loglik on the
+        # host (PCIe-inclusive; it is never `value`)
+        adev = dev
+        if batched:
+            t_a = time.perf_counter()
+            reps_a = 3
+            for _ in range(reps_a):
+                adev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
+            dt_a = (time.perf_counter() - t_a) / reps_a
+            extra['api_fits_per_sec'] = round(wl['B'] / dt_a, 2)
+            extra['api_note'] = 'cgp_batch_fit with host arrays in (upload of all %d objects) and results out, one handle' % wl['B']
+        else:
+            def api_one():
+                adev.set_data(wl['dim'], wl['x'], wl['y'])
+                return adev.fit(wl['kp'], diag, wl['xnew'], None, 0.)
+            api_one()
+            t_a = time.perf_counter()
+            reps_a = 3
+            for _ in range(reps_a):
+                api_one()
+            dt_1 = (time.perf_counter() - t_a) / reps_a
+            extra['api_single_fit_ms'] = round(dt_1 * 1e3, 4)
+            extra['api_single_fits_per_sec'] = round(1. / dt_1, 2)
+            if lock > 1:
+                bd = all_devs[0]
+                t_a = time.perf_counter()
+                for _ in range(reps_a):
+                    bd.batch_fit(wl['dim'], [o['x'] for o in objs], [o['y'] for o in objs], bdiags, wl['kp'], wl['xnew'],
+                                 None, 0.)
+                dt_a = (time.perf_counter() - t_a) / reps_a
+                extra['api_fits_per_sec'] = round(lock / dt_a, 2)
+                extra['api_note'] = ('cgp_batch_fit, %d objects per call: host arrays in (coordinates, residuals, '
+                                     'diagonals, grid), mu / var / loglik back on the host, ONE handle; '
+                                     'api_single_*: cgp_fit_set_data + cgp_fit of one object' % lock)
+            else:
+                extra['api_fits_per_sec'] = extra['api_single_fits_per_sec']
     if rank == 0:
         if extra.get('assemble_K_GBs'):
             # second roofline object: the covariance build (K1), HBM-write bound by its algorithmic bytes
@@ -407,7 +594,10 @@ def main():
         line = dict(metric='gp_fits_per_sec', value=round(value, 4), unit='fits/s', n_gpus=n_gpus,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
-                    config=dict(workload=wl['label'], n=wl['n'], m=wl['m'], dim=wl['dim'],
+                    config=dict(workload=wl['label'] + ((', %d distinct objects per lock-step launch sequence x %d handles'
+                                                         % (lock, nstreams)) if (lock > 1 and not batched and 'sweep' not in wl)
+                                                        else ''),
+                                n=wl['n'], m=wl['m'], dim=wl['dim'],
                                 fits_per_step_per_gpu=units_per_step,
                                 fits_in_flight_per_gpu=nstreams * (wl['B'] if batched else lock),
                                 objects_per_launch_sequence=(wl['B'] if batched else lock), handles_per_gpu=nstreams,
@@ -418,8 +608,9 @@ def main():
             line['cpu_baseline'] = cpu_baseline(wl)
         line['extra'] = extra
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == '__main__':

@@ -20,9 +20,13 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
-    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_sweep_loglik', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_sweep_loglik',
+    'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_allgather', 'cgp_comm_allreduce',
+    'cgp_sweep_loglik_sharded', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
+COMM_ID_BYTES = 128
+OP_SUM, OP_MAX = 0, 1
 
 
 class HipUnavailable(RuntimeError):
@@ -73,12 +77,28 @@ def load_library():
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
         lib.cgp_batch_fit_grad.argtypes = [vp, _dp, _dp, ctypes.POINTER(ctypes.c_int32), _dp]
         lib.cgp_sweep_loglik.argtypes = [vp, _i64, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int32)]
+        lib.cgp_comm_unique_id.argtypes = [ctypes.c_char_p]
+        lib.cgp_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        lib.cgp_comm_destroy.argtypes = [vp]
+        lib.cgp_comm_allgather.argtypes = [vp, _dp, _i64, _dp]
+        lib.cgp_comm_allreduce.argtypes = [vp, _dp, _i64, ctypes.c_int]
+        lib.cgp_sweep_loglik_sharded.argtypes = [vp, _i64, _dp, _dp, _i64, _dp, ctypes.POINTER(ctypes.c_int32)]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
         lib.cgp_bench_fit_objects.argtypes = [vp, ctypes.c_int, _i64, _dp]
         lib.cgp_microbench.argtypes = [vp, _dp, _dp]
         lib.cgp_selftest_mfma.argtypes = [vp]
         _lib = lib
         return lib
+
+
+def comm_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+    lib = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    st = lib.cgp_comm_unique_id(buf)
+    if st != 0:
+        raise HipUnavailable('cgp_comm_unique_id failed (status %d): librccl.so.1 missing?' % st)
+    return buf.raw
 
 
 def device_count():
@@ -123,6 +143,7 @@ class Device(object):
         self.generation = 0
         self.batch_generation = 0       # same for the resident batch
         self._batch = None
+        self.comm_rank, self.comm_world = 0, 1
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -336,6 +357,48 @@ class Device(object):
         st = self._lib.cgp_sweep_loglik(self._h, P, _ptr(kps), _ptr(dg), _ptr(ll),
                                         info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
         self._check(st, 'cgp_sweep_loglik')
+        return ll, info
+
+    # ---- multi-GPU (RCCL inside the library) -----------------------------------------
+    def comm_init(self, rank, world, uid):
+        """Join the RCCL communicator identified by the 128-byte `uid` (collective over all ranks)."""
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError('the RCCL unique id has %d bytes' % COMM_ID_BYTES)
+        self._check(self._lib.cgp_comm_init(self._h, int(rank), int(world), bytes(uid)), 'cgp_comm_init')
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._lib.cgp_comm_destroy(self._h), 'cgp_comm_destroy')
+
+    def comm_allgather(self, send):
+        """send: float64 array of the same size on every rank; returns (world, send.size)."""
+        send = _f64(send).ravel()
+        recv = np.empty((self.comm_world, send.size))
+        self._check(self._lib.cgp_comm_allgather(self._h, _ptr(send), send.size, _ptr(recv)), 'cgp_comm_allgather')
+        return recv
+
+    def comm_allreduce(self, buf, op=OP_SUM):
+        buf = _f64(buf).ravel().copy()
+        self._check(self._lib.cgp_comm_allreduce(self._h, _ptr(buf), buf.size, int(op)), 'cgp_comm_allreduce')
+        return buf
+
+    def comm_barrier(self):
+        self._check(self._lib.cgp_comm_allreduce(self._h, None, 0, OP_SUM), 'cgp_comm_allreduce')
+
+    def sweep_loglik_sharded(self, kps, diag=None, chunk=0):
+        """cgp_sweep_loglik over the ranks of this handle's communicator: the FULL (P, 7) table on every rank,
+        the complete (loglik[P], info[P]) back on every rank (one ncclAllGather, device to device)."""
+        kps = _f64(kps)
+        if kps.ndim != 2 or kps.shape[1] != 7:
+            raise ValueError('kps must have shape (P, 7)')
+        dg = None if diag is None else _f64(diag, (self.n,))
+        P = kps.shape[0]
+        ll = np.empty(P)
+        info = np.zeros(P, dtype=np.int32)
+        self.batch_generation += 1
+        st = self._lib.cgp_sweep_loglik_sharded(self._h, P, _ptr(kps), _ptr(dg), int(chunk), _ptr(ll),
+                                                info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        self._check(st, 'cgp_sweep_loglik_sharded')
         return ll, info
 
     # ---- measurement ---------------------------------------------------------------

@@ -10,8 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 namespace {
 
@@ -76,8 +80,37 @@ enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_G
 
 }  // namespace
 
+// CGP_* diagnostic switches, read ONCE per handle at cgp_create
+struct CgpEnv {
+    int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
+    long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false;
+    void read() {
+        auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
+        bulk_cap = (int)num("CGP_BULK_CAP", 0);
+        k4_waves = (int)num("CGP_K4_WAVES", 0);
+        jac_inner = (int)num("CGP_JAC_INNER", 1);
+        bigtile = num("CGP_BIGTILE", GEMM_BIG_TILE_THRESHOLD);
+        gemm_chunk = num("CGP_GEMM_CHUNK", 0);
+        no_graph = getenv("CGP_NO_GRAPH") != nullptr;
+        lookahead = getenv("CGP_LOOKAHEAD") != nullptr;
+        stream2 = getenv("CGP_STREAM2") != nullptr;
+        debug = getenv("CGP_DEBUG") != nullptr;
+        jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
+    }
+};
+
 struct cgp_handle {
     int device = 0;
+    CgpEnv env;
+    // RCCL communicator of this rank (one process per GPU): created by cgp_comm_init, used on h->stream
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    DevBuf csend, crecv;
+    // kernel parameters of the factor left by the last cgp_fit / cgp_fit_grad: cgp_fit_predict and
+    // cgp_fit_fetch re-upload them, other entry points may have overwritten the shared slot meanwhile
+    KParams fit_kp;
+    bool have_fit_kp = false;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
     std::vector<hipEvent_t> fork_events;
@@ -203,14 +236,18 @@ struct StageScope {
 };
 
 int leaf_attr_once(cgp_handle* h) {
-    static bool done_dev[64] = {false};          // the attribute is per device
-    bool& done = done_dev[h->device & 63];
-    if (done) return 0;
-    HIPCHK(hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trsm_panel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS));
-    done = true;
+    // the attribute is per device; handles may be driven from several host threads (device_pool)
+    static std::once_flag once_dev[64];
+    static hipError_t err_dev[64];
+    const int d = h->device & 63;
+    std::call_once(once_dev[d], [d]() {
+        hipError_t e = hipFuncSetAttribute((const void*)k_potrf_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        err_dev[d] = e;
+    });
+    HIPCHK(err_dev[d]);
     return 0;
 }
 
@@ -221,15 +258,15 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
                 hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
-    if (bulk_cap == 0 && B == 1 && tile_skip == 0 && !ktri && getenv("CGP_BULK_CAP") && rows % 128 == 0 && cols % 128 == 0) {
+    if (bulk_cap == 0 && B == 1 && tile_skip == 0 && !ktri && h->env.bulk_cap > 0 && rows % 128 == 0 && cols % 128 == 0) {
         // experiment: large updates as persistent 128 x 128 tiles on at most CGP_BULK_CAP workgroups
         const long nt_ = cols / 128, tl = tri ? nt_ * (nt_ + 1) / 2 + (rows / 128 - nt_) * nt_ : (rows / 128) * nt_;
-        if (tl >= 512) bulk_cap = atoi(getenv("CGP_BULK_CAP"));
+        if (tl >= 512) bulk_cap = h->env.bulk_cap;
     }
     const long nt128_ = cols / 128;
     const long tiles_big_ = (tri ? nt128_ * (nt128_ + 1) + (rows / 128 - nt128_) * (cols / 64) : (rows / 128) * (cols / 64));
     const bool big_form = bulk_cap == 0 &&
-        tiles_big_ * B >= (getenv("CGP_BIGTILE") ? atol(getenv("CGP_BIGTILE")) : GEMM_BIG_TILE_THRESHOLD);
+        tiles_big_ * B >= h->env.bigtile;
     StageScope sc(h, big_form ? ST_GEMM_BIG : ST_GEMM);
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
@@ -259,7 +296,7 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const int skip = tile_skip ? 2 : 0;
         // CGP_GEMM_CHUNK=n: issue the update in launches of n tiles (one round of the chip each), so that the
         // leaf kernels of other fits in flight find free CUs at every chunk boundary
-        static const long chunk = getenv("CGP_GEMM_CHUNK") ? atol(getenv("CGP_GEMM_CHUNK")) : 0;
+        const long chunk = h->env.gemm_chunk;
         if (chunk > 0 && B == 1 && tiles_big - skip > chunk + chunk / 2) {
             for (long t0 = skip; t0 < tiles_big; t0 += chunk) {
                 const long t1 = std::min(t0 + chunk, tiles_big);
@@ -366,7 +403,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             // waves per workgroup that still puts the whole launch on the chip at once (a single fit: 4 waves,
             // 1 per SIMD, shortest chain; a batch of small problems: up to 16, rows of 256)
             const long rows = Re - r0, cus = 256;
-            const int force = getenv("CGP_K4_WAVES") ? atoi(getenv("CGP_K4_WAVES")) : 0;
+            const int force = h->env.k4_waves;
             int w = 4;
             if (force) w = force;
             else if ((rows / 64) * P.B > cus) w = ((rows / 128) * P.B > cus && rows % 256 == 0) ? 16 : 8;
@@ -480,7 +517,8 @@ int cgp_create(int device, cgp_handle** out) {
     h->device = device;
     // the second stream exists only for the opt-in look-ahead experiment (it also shifts how the runtime deals
     // streams onto its hardware queues)
-    const bool want2 = getenv("CGP_LOOKAHEAD") != nullptr || getenv("CGP_STREAM2") != nullptr;
+    h->env.read();
+    const bool want2 = h->env.lookahead || h->env.stream2;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         (want2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess)) {
         delete h;
@@ -492,9 +530,10 @@ int cgp_create(int device, cgp_handle** out) {
 
 int cgp_destroy(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
+    (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf* all[] = {&h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
+    DevBuf* all[] = {&h->csend, &h->crecv, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
@@ -540,6 +579,21 @@ int upload_kp(cgp_handle* h, const double* kp, double kss_noise) {
     k.kss_noise = kss_noise;
     HIPCHK(hipMemcpyAsync(h->bkp.p, &k, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// remember the parameters a resident factor was built with / put them back into the shared slot
+void remember_fit_kp(cgp_handle* h, const double* kp, double kss_noise) {
+    KParams& k = h->fit_kp;
+    k.amp_train = kp[0]; k.amp_cross = kp[1]; k.p0 = kp[2]; k.p1 = kp[3]; k.p2 = kp[4]; k.p3 = kp[5];
+    k.nug2 = kp[6];
+    k.kss_noise = kss_noise;
+    h->have_fit_kp = true;
+}
+
+int restore_fit_kp(cgp_handle* h, double kss_noise) {
+    h->fit_kp.kss_noise = kss_noise;
+    HIPCHK(hipMemcpyAsync(h->bkp.p, &h->fit_kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -626,7 +680,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
 // call instead of 200.  Everything that changes between calls (kernel parameters, kss_noise,
 // diagonal, coordinates) lives in HBM buffers the graph only points to.
 int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
-    if (!h->use_graph || h->profiling || getenv("CGP_NO_GRAPH")) return device_fit_eager(h, P, m, has_mean);
+    if (!h->use_graph || h->profiling || h->env.no_graph) return device_fit_eager(h, P, m, has_mean);
     cgp_handle::GraphKey key;
     std::memset(&key, 0, sizeof(key));
     const void* ptrs[16] = {P.M, P.x, P.r, P.diag, P.xnew, (const void*)(intptr_t)(P.kps + 2 * (P.sx == 0)), P.wsW, P.ldp, P.info, P.ns, P.mean, P.mu, P.var,
@@ -643,16 +697,16 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
     // capture (a failed capture falls back to eager launches)
     cgp_handle::CachedGraph cg;
     cg.key = key;
-    if (getenv("CGP_LOOKAHEAD") && !h->stream2 &&
+    if (h->env.lookahead && !h->stream2 &&
         hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) h->stream2 = nullptr;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->trk.active = getenv("CGP_LOOKAHEAD") != nullptr && h->stream2;      // opt-in: measured slower
+    h->trk.active = h->env.lookahead && h->stream2;      // opt-in: measured slower
     h->fork_used = 0;
     int st = device_fit_eager(h, P, m, has_mean);
     h->trk.active = false;
     hipError_t e = hipStreamEndCapture(h->stream, &cg.graph);
     if (st < 0 || e != hipSuccess || !cg.graph) {
-        if (getenv("CGP_DEBUG")) fprintf(stderr, "cgp: graph capture failed (st=%d, %s), eager launches\n", st, hipGetErrorString(e));
+        if (h->env.debug) fprintf(stderr, "cgp: graph capture failed (st=%d, %s), eager launches\n", st, hipGetErrorString(e));
         if (cg.graph) (void)hipGraphDestroy(cg.graph);
         (void)hipGetLastError();
         h->use_graph = false;
@@ -670,7 +724,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
         h->graphs.erase(h->graphs.begin());
     }
     h->graphs.push_back(cg);
-    if (getenv("CGP_DEBUG")) fprintf(stderr, "cgp: captured fit graph (B=%d Np=%ld R=%ld m=%ld)\n", P.B, P.Np, P.R, m);
+    if (h->env.debug) fprintf(stderr, "cgp: captured fit graph (B=%d Np=%ld R=%ld m=%ld)\n", P.B, P.Np, P.R, m);
     HIPCHK(hipGraphLaunch(cg.exec, h->stream));
     return 0;
 }
@@ -735,6 +789,7 @@ int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resi
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_data = true;
     h->factored = false;
+    h->have_fit_kp = false;
     return CGP_OK;
 }
 
@@ -747,6 +802,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     const long Mp = round_up(m + 1, NB);
     CHK(bind_single(h, Mp, false));
     CHK(upload_kp(h, kp, kss_noise));
+    remember_fit_kp(h, kp, kss_noise);
     if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));   // NULL: keep the resident one
     CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
     CHK(upload_padded(h, h->bmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
@@ -792,8 +848,9 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     P.xnew = (double*)h->bxnew.p; P.sxn = 0;
     P.mean = (double*)h->bmean.p;
     P.mu = (double*)h->bmu.p; P.var = (double*)h->bvar.p; P.sOut = Mp;
-    HIPCHK(hipMemcpyAsync((char*)h->bkp.p + offsetof(KParams, kss_noise), &kss_noise, sizeof(double),
-                          hipMemcpyHostToDevice, h->stream));
+    // the factor's own parameters go back into the shared slot: cgp_rbf / batch fits / sweeps on this handle may
+    // have overwritten it since the fit (the host copy is staged before the call returns)
+    CHK(restore_fit_kp(h, kss_noise));
     CHK(launch_assemble_cross(h, P.dim, 1, P.M + P.Np * ld, ld, P.sM, P.x, 0, P.xnew, 0, P.ns, P.Np, Mp, m));
     // rows are solved in 64-row groups, so the raw residual row rides along again with H
     CHK(put_resid_row(h, P));
@@ -835,6 +892,7 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     const long tall = P.Np + NB;
     CHK(bind_single(h, tall, false));
     CHK(upload_kp(h, kp, 0.));
+    remember_fit_kp(h, kp, 0.);
     if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
     CHK(ensure(h, h->bmu, tall * sizeof(double)));
     CHK(ensure(h, h->bvar, tall * sizeof(double)));
@@ -950,7 +1008,7 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     hipLaunchKernelGGL(k_jac_identity, dim3(512), dim3(256), 0, h->stream, V, ld, (int)Np);
     HIPCHK(hipGetLastError());
     const int max_sweeps = 40;
-    if (n <= JP && !getenv("CGP_JAC_NO_SMALL")) {
+    if (n <= JP && !h->env.jac_no_small) {
         // the whole problem is one pivot matrix: one launch
         hipLaunchKernelGGL(k_jac_small, dim3(1), dim3(256), 0, h->stream, K, V, ld, (const JacStat*)st, 60);
         HIPCHK(hipGetLastError());
@@ -967,7 +1025,7 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     // cyclic sweeps over a pivot matrix per visit: 1 (classical block-cyclic Jacobi) is the fastest -- the
     // number of outer sweeps (17-19 on RBF + noise matrices) does not go down when the pivots are
     // diagonalised further (measured: 12 -> 1 cuts N = 2048 from 500 to 270 ms)
-    const int inner_cap = getenv("CGP_JAC_INNER") ? atoi(getenv("CGP_JAC_INNER")) : 1;
+    const int inner_cap = h->env.jac_inner;
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         HIPCHK(hipMemsetAsync((char*)st + offsetof(JacStat, rotations), 0, sizeof(int), h->stream));
@@ -984,7 +1042,7 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
         int rot = 0;
         HIPCHK(hipMemcpyAsync(&rot, (char*)st + offsetof(JacStat, rotations), sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (getenv("CGP_DEBUG")) fprintf(stderr, "cgp: eigen sweep %d: %d pivot blocks rotated\n", sweep, rot);
+        if (h->env.debug) fprintf(stderr, "cgp: eigen sweep %d: %d pivot blocks rotated\n", sweep, rot);
         if (rot == 0) break;
     }
     h->last_sweeps = sweep + 1;
@@ -1035,7 +1093,8 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out) {
     if (!out) return fail(h, CGP_E_ARG, "cgp_fit_fetch: null output");
     Prob& P = h->P;
     if (which == CGP_MAT_K) {
-        if (!h->have_data || !h->bdiag.p) return fail(h, CGP_E_STATE, "cgp_fit_fetch(K): no fit yet");
+        if (!h->have_data || !h->bdiag.p || !h->have_fit_kp) return fail(h, CGP_E_STATE, "cgp_fit_fetch(K): no fit yet");
+        CHK(restore_fit_kp(h, h->fit_kp.kss_noise));
         CHK(ensure(h, h->bC, (size_t)P.Np * P.Np * sizeof(double)));
         CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, P.Np, 0, P.x, 0, P.diag, 0, P.ns, P.Np, false, true));
         return square_to_host(h, (double*)h->bC.p, P.Np, P.n, 0, out);
@@ -1117,6 +1176,7 @@ int cgp_fit_svd(cgp_handle* h, const double* kp, const double* diag, const doubl
     CHK(bind_single(h, Mp, false));
     h->factored = false;                                 // the Cholesky factor of this handle is gone
     CHK(upload_kp(h, kp, kss_noise));
+    remember_fit_kp(h, kp, kss_noise);
     if (diag) CHK(upload_padded(h, h->bdiag, diag, (size_t)P.n, (size_t)P.Np));
     CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
     CHK(upload_padded(h, h->bmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
@@ -1320,11 +1380,8 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
 
 // Log-likelihood of the resident object (cgp_fit_set_data) for P kernel-parameter sets in ONE launch sequence:
 // P matrices in HBM, coordinates / residual / diagonal shared (batch strides 0), one KParams per candidate.
-int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double* diag, double* loglik, int32_t* info) {
-    CHK(begin_call(h));
-    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_sweep_loglik: no data (call cgp_fit_set_data)");
-    if (np_ <= 0 || np_ > CGP_MAX_SWEEP || !kp || !loglik) return fail(h, CGP_E_ARG, "cgp_sweep_loglik: bad argument");
-    const long B = np_;
+// sweep_launch leaves loglik / logdet in Q.scal ([B][2]) and the info words in Q.info, on the device.
+static int sweep_launch(cgp_handle* h, long B, const double* kp, const double* diag) {
     Prob& Q = h->Q;
     h->have_batch = false;                     // the resident batch (if any) loses its buffers
     Q = Prob();
@@ -1366,6 +1423,22 @@ int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double*
     Q.mu = (double*)h->qmu.p; Q.var = (double*)h->qvar.p; Q.sOut = NB;
     Q.scal = (double*)h->qscal.p;
     CHK(device_fit(h, Q, 0, false));
+    h->last_was_batch = true;
+    h->last_m = 0;
+    h->last_has_mean = false;
+    h->last_kss_noise = 0.;
+    h->factored = false;
+    h->have_fit_kp = false;                    // slot 0 of the parameter block now belongs to candidate 0
+    return 0;
+}
+
+int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double* diag, double* loglik, int32_t* info) {
+    CHK(begin_call(h));
+    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_sweep_loglik: no data (call cgp_fit_set_data)");
+    if (np_ <= 0 || np_ > CGP_MAX_SWEEP || !kp || !loglik) return fail(h, CGP_E_ARG, "cgp_sweep_loglik: bad argument");
+    const long B = np_;
+    CHK(sweep_launch(h, B, kp, diag));
+    Prob& Q = h->Q;
     std::vector<double> sc((size_t)B * 2);
     std::vector<int> hinfo(B);
     HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1375,13 +1448,191 @@ int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double*
         loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
     }
-    h->last_was_batch = true;
-    h->last_m = 0;
-    h->last_has_mean = false;
-    h->last_kss_noise = 0.;
-    h->factored = false;
     return CGP_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL: librccl.so.1 is opened on first use, so the single-GPU path has no dependency on it
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.so) break;
+        }
+        if (!r.so) { r.err = std::string("dlopen(librccl.so.1): ") + dlerror(); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p) r.err = std::string("librccl: missing ") + n; return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+
+#define NCCLCHK(call)                                                                      \
+    do {                                                                                   \
+        ncclResult_t r_ = (call);                                                          \
+        if (r_ != ncclSuccess) {                                                           \
+            h->err = std::string(#call) + ": " + (R->GetErrorString ? R->GetErrorString(r_) : "?"); \
+            return CGP_E_HIP;                                                              \
+        }                                                                                  \
+    } while (0)
+
+int comm_ready(cgp_handle* h, Rccl*& R) {
+    R = rccl();
+    if (!R->err.empty()) return fail(h, CGP_E_STATE, R->err.c_str());
+    if (!h->comm) return fail(h, CGP_E_STATE, "no communicator on this handle (call cgp_comm_init)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgp_comm_unique_id(void* id_out) {
+    if (!id_out) return CGP_E_ARG;
+    Rccl* R = rccl();
+    if (!R->err.empty()) return CGP_E_STATE;
+    static_assert(sizeof(ncclUniqueId) == CGP_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return CGP_E_HIP;
+    std::memcpy(id_out, &id, sizeof(id));
+    return CGP_OK;
+}
+
+int cgp_comm_init(cgp_handle* h, int rank, int world, const void* id) {
+    CHK(begin_call(h));
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, CGP_E_ARG, "cgp_comm_init: bad argument");
+    if (h->comm) return fail(h, CGP_E_STATE, "cgp_comm_init: the handle already has a communicator");
+    Rccl* R = rccl();
+    if (!R->err.empty()) return fail(h, CGP_E_STATE, R->err.c_str());
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCLCHK(R->CommInitRank(&h->comm, world, uid, rank));     // on the current device = h->device (begin_call)
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return CGP_OK;
+}
+
+int cgp_comm_destroy(cgp_handle* h) {
+    if (!h) return CGP_E_ARG;
+    if (!h->comm) return CGP_OK;
+    Rccl* R = rccl();
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    ncclComm_t c = h->comm;
+    h->comm = nullptr;
+    h->comm_world = 1;
+    h->comm_rank = 0;
+    NCCLCHK(R->CommDestroy(c));
+    return CGP_OK;
+}
+
+int cgp_comm_allgather(cgp_handle* h, const double* send, int64_t count, double* recv) {
+    CHK(begin_call(h));
+    Rccl* R;
+    CHK(comm_ready(h, R));
+    if (count < 0 || (count > 0 && (!send || !recv))) return fail(h, CGP_E_ARG, "cgp_comm_allgather: bad argument");
+    if (count == 0) return CGP_OK;
+    const size_t bytes = (size_t)count * sizeof(double);
+    CHK(ensure(h, h->csend, bytes));
+    CHK(ensure(h, h->crecv, bytes * h->comm_world));
+    HIPCHK(hipMemcpyAsync(h->csend.p, send, bytes, hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(R->AllGather(h->csend.p, h->crecv.p, (size_t)count, ncclDouble, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(recv, h->crecv.p, bytes * h->comm_world, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
+
+int cgp_comm_allreduce(cgp_handle* h, double* buf, int64_t count, int op) {
+    CHK(begin_call(h));
+    Rccl* R;
+    CHK(comm_ready(h, R));
+    if (count < 0 || (count > 0 && !buf) || (op != CGP_OP_SUM && op != CGP_OP_MAX))
+        return fail(h, CGP_E_ARG, "cgp_comm_allreduce: bad argument");
+    const size_t n = (size_t)std::max<int64_t>(count, 1);      // count = 0: one dummy element = a barrier
+    CHK(ensure(h, h->csend, n * sizeof(double)));
+    if (count > 0) HIPCHK(hipMemcpyAsync(h->csend.p, buf, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(hipMemsetAsync(h->csend.p, 0, sizeof(double), h->stream));
+    NCCLCHK(R->AllReduce(h->csend.p, h->csend.p, n, ncclDouble, op == CGP_OP_MAX ? ncclMax : ncclSum, h->comm, h->stream));
+    if (count > 0) HIPCHK(hipMemcpyAsync(buf, h->csend.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
+
+}  // extern "C"
+
+// {loglik, info} of the B candidates of the last sweep launch -> slots [off, off + B) of the send block
+__global__ void k_pack_sweep(const double* __restrict__ scal, const int* __restrict__ info, double* __restrict__ out,
+                             long off, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        out[(off + b) * 2] = scal[2 * b];
+        out[(off + b) * 2 + 1] = (double)info[b];
+    }
+}
+
+extern "C" {
+
+int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, const double* diag, int64_t chunk,
+                             double* loglik, int32_t* info) {
+    CHK(begin_call(h));
+    Rccl* R;
+    CHK(comm_ready(h, R));
+    if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_sweep_loglik_sharded: no data (call cgp_fit_set_data)");
+    if (np_total <= 0 || !kp || !loglik) return fail(h, CGP_E_ARG, "cgp_sweep_loglik_sharded: bad argument");
+    if (chunk <= 0 || chunk > CGP_MAX_SWEEP) chunk = CGP_MAX_SWEEP;
+    const long W = h->comm_world, r = h->comm_rank;
+    const long base = np_total / W, extra = np_total % W, per = base + (extra ? 1 : 0);
+    auto lo_of = [&](long q) { return q * base + std::min(q, extra); };
+    const long lo = lo_of(r), hi = lo_of(r + 1);
+    CHK(ensure(h, h->csend, (size_t)per * 2 * sizeof(double)));
+    CHK(ensure(h, h->crecv, (size_t)per * 2 * W * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->csend.p, 0, (size_t)per * 2 * sizeof(double), h->stream));
+    for (long c0 = lo; c0 < hi; c0 += chunk) {
+        const long B = std::min<long>(chunk, hi - c0);
+        CHK(sweep_launch(h, B, kp + 7 * c0, c0 == lo ? diag : nullptr));
+        hipLaunchKernelGGL(k_pack_sweep, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, (const double*)h->Q.scal,
+                           (const int*)h->Q.info, (double*)h->csend.p, c0 - lo, (int)B);
+        HIPCHK(hipGetLastError());
+    }
+    // the one collective of the path: per-candidate results of every rank, device to device
+    NCCLCHK(R->AllGather(h->csend.p, h->crecv.p, (size_t)per * 2, ncclDouble, h->comm, h->stream));
+    std::vector<double> all((size_t)per * 2 * W);
+    HIPCHK(hipMemcpyAsync(all.data(), h->crecv.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (long q = 0; q < W; ++q)
+        for (long u = lo_of(q); u < lo_of(q + 1); ++u) {
+            const double* e = &all[(size_t)(q * per + (u - lo_of(q))) * 2];
+            loglik[u] = e[0];
+            if (info) info[u] = (int32_t)e[1];
+        }
+    return CGP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms) {
     CHK(begin_call(h));

@@ -51,6 +51,8 @@ SVD_VIA_CHOLESKY_WHEN_PD = 'auto'
 #: objects per batched launch sequence are capped so that B * (Np + 128) * Np * 8 bytes
 #: stays below this (HBM is 288 GB; leave room for several handles)
 BATCH_BYTES_LIMIT = 64 << 30
+#: the batch index travels in gridDim.z (<= 65535)
+MAX_BATCH_OBJECTS = 65535
 
 
 class _LazyList(object):
@@ -160,8 +162,10 @@ class Gaussian_process(object):
         else:
             self.y0 = np.zeros(self.N_sn)
         self.as_the_same_time = True
-        self._resident = None       # (device generation, object index) of the data in HBM
+        self._resident = None       # _res_token of the object whose data is in HBM
         self._factor_token = None   # + (kp, nugget) of the factor in HBM
+        self._batch_resident = None
+        self._cov_state = None
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -184,23 +188,48 @@ class Gaussian_process(object):
             return bound + float(nugget) ** 2 > 1e-14
         return bool(SVD_VIA_CHOLESKY_WHEN_PD)
 
+    def _res_token(self, sn):
+        """Identity of object sn's data in HBM: the handle's data generation, the index and the ids of the
+        arrays it was uploaded from (REPLACING gp.y[sn] / gp.Time[sn] / gp.y_err[sn] by new arrays is
+        noticed; mutating them in place is not -- call invalidate() after that)."""
+        return (self.device.generation, sn, id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn]))
+
+    def _make_resident(self, sn):
+        """Upload object sn unless it already is the resident object of the handle; returns the diagonal
+        vector to pass along with the next fit (None = keep the resident one)."""
+        dev = self.device
+        if self._resident == self._res_token(sn):
+            return None
+        dev.set_data(self._dim, self.Time[sn], self._resid(sn))
+        self._resident = self._res_token(sn)
+        return self._diag(sn)
+
+    def invalidate(self):
+        """Forget what is resident in HBM (call after mutating y / y_err / Time / y0 IN PLACE: the reference
+        re-reads them on every call, Gaussian_process.py:207-211; here they are uploaded once)."""
+        self._resident = None
+        self._factor_token = None
+        self._batch_resident = None
+
     def _my_objects(self):
         if self.comm is None:
             return list(range(self.N_sn))
         return self.comm.my_units(self.N_sn)
 
-    def _batch_chunks(self, objs, grad=False):
+    def _batch_chunks(self, objs, grad=False, m=0):
         """Split object indices into launch sequences: objects are bucketed by their padded size (multiples of
         128), so that one large object does not inflate the matrices of the small ones, and a bucket is cut where
-        its batch would exceed BATCH_BYTES_LIMIT (the gradient needs 3 Np + 128 rows of Np doubles per object:
-        K, the identity rows, K^-1).  Chunks come largest size first; inside a chunk the object order is kept."""
+        its batch would exceed BATCH_BYTES_LIMIT -- Np + round_up(m + 1, 128) rows of Np doubles per object for a
+        fit with m prediction points, 3 Np + 128 for the gradient (K, the identity rows, K^-1) -- or
+        MAX_BATCH_OBJECTS (the batch index is a grid dimension).  Chunks come largest size first; inside a
+        chunk the object order is kept."""
         buckets = {}
         for sn in objs:
             buckets.setdefault((len(self.y[sn]) + 127) // 128 * 128, []).append(sn)
         chunks = []
         for np_ in sorted(buckets, reverse=True):
-            rows = (3 * np_ + 128) if grad else (np_ + 128)
-            per = max(1, int(BATCH_BYTES_LIMIT // (rows * np_ * 8)))
+            rows = (3 * np_ + 128) if grad else (np_ + (int(m) + 1 + 127) // 128 * 128)
+            per = max(1, min(MAX_BATCH_OBJECTS, int(BATCH_BYTES_LIMIT // (rows * np_ * 8))))
             members = buckets[np_]
             for lo in range(0, len(members), per):
                 chunks.append(members[lo:lo + per])
@@ -210,32 +239,23 @@ class Gaussian_process(object):
         """One cgp_fit for object sn; its coordinates / residual are uploaded only when another
         object (or another GP on the same handle) replaced them."""
         dev = self.device
-        diag = None                       # keep the resident diagonal vector ...
-        if self._resident != (dev.generation, sn):
-            dev.set_data(self._dim, self.Time[sn], self._resid(sn))
-            self._resident = (dev.generation, sn)
-            diag = self._diag(sn)         # ... unless the object was (re)uploaded
+        diag = self._make_resident(sn)    # None keeps the resident diagonal vector
         self._factor_token = None
         out = dev.fit(kp, diag, grid, new_y0, kss_noise)
-        self._factor_token = (dev.generation, sn, kp.tobytes(), float(nugget))
+        self._factor_token = self._res_token(sn) + (kp.tobytes(), float(nugget))
         return out
 
     def _ensure_factor(self, sn, kp, nugget):
         """Make object sn's factor (for kp, nugget) the one in HBM; re-fit if it was replaced."""
-        dev = self.device
-        if (self._resident == (dev.generation, sn)
-                and self._factor_token == (dev.generation, sn, kp.tobytes(), float(nugget))):
+        tok = self._res_token(sn)
+        if self._resident == tok and self._factor_token == tok + (kp.tobytes(), float(nugget)):
             return
         self._fit_single(sn, kp, nugget)
 
     def _fit_single_svd(self, sn, kp, grid=None, new_y0=None, kss_noise=0., want_cov=False):
         """One cgp_fit_svd (the reference's default svd_method=True algorithm) for object sn."""
         dev = self.device
-        diag = None
-        if self._resident != (dev.generation, sn):
-            dev.set_data(self._dim, self.Time[sn], self._resid(sn))
-            self._resident = (dev.generation, sn)
-            diag = self._diag(sn)
+        diag = self._make_resident(sn)
         self._factor_token = None              # the handle's Cholesky factor does not survive this call
         return dev.fit_svd(kp, diag, grid, new_y0, kss_noise, SVD_THRESHOLD, want_cov)
 
@@ -250,16 +270,24 @@ class Gaussian_process(object):
             Nugget = self.nugget
             hyperparameter = Hyperparameter
         objs = self._my_objects()
-        if svd_method and self._svd_by_cholesky(Nugget):
+        per_obj = None
+        if not svd_method or self._svd_by_cholesky(Nugget):
+            # Cholesky route; every rank learns whether ANY rank met a non-positive pivot before the gather, so
+            # that all of them raise (svd_method=False) or fall back to the eigensolver route together
+            err = None
             try:
-                return self.compute_log_likelihood(Hyperparameter, svd_method=False)
-            except np.linalg.LinAlgError:
-                pass
-        if svd_method:
+                per_obj = self._loglik_chol(objs, hyperparameter, Nugget)
+            except np.linalg.LinAlgError as e:
+                err = e
+            failed = err is not None if self.comm is None else self.comm.agree_any(err is not None)
+            if failed:
+                per_obj = None
+                if not svd_method:
+                    raise err if err is not None else np.linalg.LinAlgError(
+                        'the matrix of an object on another rank is not positive definite')
+        if per_obj is None:
             kp = _kparams(self._dim, hyperparameter, Nugget)
             per_obj = [self._fit_single_svd(sn, kp)[0] for sn in objs]
-        else:
-            per_obj = self._loglik_chol(objs, hyperparameter, Nugget)
         if self.comm is not None:
             per_obj = self.comm.gather_units(np.asarray(per_obj, dtype=np.float64), self.N_sn)
         log_likelihood = 0
@@ -270,11 +298,14 @@ class Gaussian_process(object):
     def _batch_upload(self, chunk):
         """Make `chunk` the resident batch of the handle (skipped when it already is)."""
         dev = self.device
-        token = (dev.batch_generation, tuple(chunk))
-        if getattr(self, '_batch_resident', None) != token:
+
+        def token():
+            return (dev.batch_generation, tuple(chunk),
+                    tuple((id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn])) for sn in chunk))
+        if getattr(self, '_batch_resident', None) != token():
             dev.batch_set_data(self._dim, [self.Time[sn] for sn in chunk], [self._resid(sn) for sn in chunk],
                                [self._diag(sn) for sn in chunk])
-            self._batch_resident = (dev.batch_generation, tuple(chunk))
+            self._batch_resident = token()
 
     def _loglik_chol(self, objs, hyperparameter, nugget):
         dev = self.device
@@ -333,14 +364,10 @@ class Gaussian_process(object):
                     rows[pos, 1 + nh] = g[-1]
             objs = []
         for k, sn in enumerate(objs):
-            diag = None
-            if self._resident != (dev.generation, sn):
-                dev.set_data(self._dim, self.Time[sn], self._resid(sn))
-                self._resident = (dev.generation, sn)
-                diag = self._diag(sn)
+            diag = self._make_resident(sn)
             self._factor_token = None
             ll, _, sums = dev.fit_grad(kp, diag)
-            self._factor_token = (dev.generation, sn, kp.tobytes(), float(Nugget))
+            self._factor_token = self._res_token(sn) + (kp.tobytes(), float(Nugget))
             if self._dim == 1:
                 g = _kernel.gradient_from_sums_1d(hyperparameter, Nugget, sums)
             else:
@@ -437,114 +464,144 @@ class Gaussian_process(object):
         self.compute_kernel_matrix()
         hyp = np.array(self.hyperparameters, dtype=np.float64)
         nugget = self.nugget
-        self.Prediction = [None] * self.N_sn
-        self.variance = [None] * self.N_sn
-        if svd_method and self._svd_by_cholesky(nugget):
-            try:
-                return self.get_prediction(new_binning=new_binning, COV=COV, svd_method=False)
-            except np.linalg.LinAlgError:
-                self.Prediction = [None] * self.N_sn
-                self.variance = [None] * self.N_sn
-        if svd_method:
+        done = False
+        if not svd_method or self._svd_by_cholesky(nugget):
+            done = self._predict_chol(hyp, nugget, must_succeed=not svd_method)
+        if not done:
             self._predict_svd(hyp, nugget, COV)
-            return
+        if COV:
+            self.get_covariance_matrix()
+
+    def _predict_chol(self, hyp, nugget, must_succeed):
+        """Cholesky route of get_prediction.  Returns False (nothing stored) when some object, on ANY rank, is not
+        positive definite and must_succeed is False; raises numpy.linalg.LinAlgError on every rank otherwise."""
         dev = self.device
         kp = _kparams(self._dim, hyp, nugget)
         kss_noise = 0. ** 2 + 0. ** 2 + nugget ** 2          # kernel(new_grid, hyp, nugget=...) :357
         objs = self._my_objects()
         shared = not self.as_the_same_time
-        if len(objs) > 1 and shared:
-            for chunk in self._batch_chunks(objs):
-                self._batch_upload(chunk)
-                _, info, mu, var = dev.batch_fit_resident(kp, xnew=self.new_binning, kss_noise=kss_noise)
-                bad = np.nonzero(info)[0]
-                if len(bad):
-                    raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
-                                                ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
-                for k, sn in enumerate(chunk):
+        pred = [None] * self.N_sn
+        variance = [None] * self.N_sn
+        err = None
+        try:
+            if len(objs) > 1 and shared:
+                m = len(self.new_binning)
+                for chunk in self._batch_chunks(objs, m=m):
+                    self._batch_upload(chunk)
+                    _, info, mu, var = dev.batch_fit_resident(kp, xnew=self.new_binning, kss_noise=kss_noise)
+                    bad = np.nonzero(info)[0]
+                    if len(bad):
+                        raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
+                                                    ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
+                    for k, sn in enumerate(chunk):
+                        new_y0 = self._new_y0(sn)
+                        self.warning_pf = new_y0
+                        pred[sn] = mu[k] + new_y0
+                        variance[sn] = var[k]
+            elif len(objs) > 1:
+                # each object on its own grid, still ONE launch sequence per chunk: grids padded to the longest
+                # (extra points repeat the last one and are dropped)
+                m_all = max(len(self._grid(sn)) for sn in objs)
+                for chunk in self._batch_chunks(objs, m=m_all):
+                    self._batch_upload(chunk)
+                    grids = [np.asarray(self._grid(sn), dtype=np.float64) for sn in chunk]
+                    m_max = max(len(g) for g in grids)
+                    padded = np.stack([np.concatenate([g, np.repeat(g[-1:], m_max - len(g), axis=0)]) for g in grids])
+                    _, info, mu, var = dev.batch_fit_resident(kp, xnew=padded, kss_noise=kss_noise,
+                                                              xnew_per_object=True)
+                    bad = np.nonzero(info)[0]
+                    if len(bad):
+                        raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
+                                                    ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
+                    for k, sn in enumerate(chunk):
+                        new_y0 = self._new_y0(sn)
+                        self.warning_pf = new_y0
+                        pred[sn] = mu[k, :len(grids[k])] + new_y0
+                        variance[sn] = var[k, :len(grids[k])].copy()
+            else:
+                for sn in objs:
                     new_y0 = self._new_y0(sn)
                     self.warning_pf = new_y0
-                    self.Prediction[sn] = mu[k] + new_y0
-                    self.variance[sn] = var[k]
-        elif len(objs) > 1:
-            # each object on its own grid, still ONE launch sequence per chunk: grids padded to the longest
-            # (extra points repeat the last one and are dropped)
-            for chunk in self._batch_chunks(objs):
-                self._batch_upload(chunk)
-                grids = [np.asarray(self._grid(sn), dtype=np.float64) for sn in chunk]
-                m_max = max(len(g) for g in grids)
-                padded = np.stack([np.concatenate([g, np.repeat(g[-1:], m_max - len(g), axis=0)]) for g in grids])
-                _, info, mu, var = dev.batch_fit_resident(kp, xnew=padded, kss_noise=kss_noise, xnew_per_object=True)
-                bad = np.nonzero(info)[0]
-                if len(bad):
-                    raise np.linalg.LinAlgError('%d-th leading minor of the array is not positive definite'
-                                                ' (object %d)' % (info[bad[0]], chunk[bad[0]]))
-                for k, sn in enumerate(chunk):
-                    new_y0 = self._new_y0(sn)
-                    self.warning_pf = new_y0
-                    self.Prediction[sn] = mu[k, :len(grids[k])] + new_y0
-                    self.variance[sn] = var[k, :len(grids[k])].copy()
-        else:
-            for sn in objs:
-                new_y0 = self._new_y0(sn)
-                self.warning_pf = new_y0
-                _, _, mu, var = self._fit_single(sn, kp, nugget, self._grid(sn), new_y0, kss_noise)
-                self.Prediction[sn] = mu
-                self.variance[sn] = var
+                    _, _, mu, var = self._fit_single(sn, kp, nugget, self._grid(sn), new_y0, kss_noise)
+                    pred[sn] = mu
+                    variance[sn] = var
+        except np.linalg.LinAlgError as e:
+            err = e
+        # agreement BEFORE the gathers: a rank that raised must not leave its peers inside a collective
+        failed = err is not None if self.comm is None else self.comm.agree_any(err is not None)
+        if failed:
+            if must_succeed:
+                raise err if err is not None else np.linalg.LinAlgError(
+                    'the matrix of an object on another rank is not positive definite')
+            return False
         if self.comm is not None:
-            self.Prediction = self.comm.gather_unit_arrays(self.Prediction, self.N_sn)
-            self.variance = self.comm.gather_unit_arrays(self.variance, self.N_sn)
+            pred = self.comm.gather_unit_arrays(pred, self.N_sn)
+            variance = self.comm.gather_unit_arrays(variance, self.N_sn)
+        self.Prediction = pred
+        self.variance = variance
 
         def make_inv(sn):
             self._ensure_factor(sn, kp, nugget)
             return dev.fetch(_lib.MAT_KINV)
 
         self.inv_kernel_matrix = _LazyList(self.N_sn, make_inv)
-        if COV:
-            self._cov_state = (kp, nugget, kss_noise)
-            self.get_covariance_matrix()
+        # recorded whatever COV says: the reference allows get_prediction(COV=False); get_covariance_matrix()
+        self._cov_state = ('chol', kp, nugget, kss_noise, {})
+        return True
 
     def get_covariance_matrix(self):
-        """self.covariance_matrix = [K(new,new; nugget) - H K^-1 H^T] (Gaussian_process.py:340-361).
-        On the Cholesky path the full (M, M) matrix is built on the device
-        (K** - W W^T, one MFMA GEMM) when an item is first read."""
+        """self.covariance_matrix = [K(new,new; nugget) - H K^-1 H^T] (Gaussian_process.py:340-361) for the
+        hyperparameters, nugget, grid and route of the LAST get_prediction.  The full (M, M) matrix is built on
+        the device when an item is first read (Cholesky route: K** - W W^T, one MFMA GEMM on the resident factor;
+        eigensolver route: K** - T H' by cgp_fit_svd, kept when get_prediction already produced it)."""
         state = getattr(self, '_cov_state', None)
         if state is None:
-            raise AttributeError('get_covariance_matrix needs get_prediction(svd_method=False) first')
-        kp, nugget, kss_noise = state
+            raise AttributeError('get_covariance_matrix needs get_prediction first')
+        route, kp, nugget, kss_noise, ready = state
         dev = self.device
 
         def make(sn):
-            self._ensure_factor(sn, kp, nugget)
             grid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
-            _, _, cov = dev.predict(grid, None, kss_noise, want_cov=True)
-            return cov
+            if route == 'chol':
+                self._ensure_factor(sn, kp, nugget)
+                _, _, cov = dev.predict(grid, None, kss_noise, want_cov=True)
+                return cov
+            if sn in ready:
+                return ready[sn]
+            return self._fit_single_svd(sn, kp, grid, None, kss_noise, want_cov=True)[5]
 
         self.covariance_matrix = _LazyList(self.N_sn, make)
 
-    def _predict_svd(self, hyp, nugget, COV):
+    def _predict_svd(self, hyp, nugget, COV=True):
         """Reference default (svd_method=True): pseudo-inverse route, one device call per object
-        (cgp_fit_svd: K, its eigen-decomposition, K^+, H K^+ r and K** - H K^+ H' stay in HBM)."""
+        (cgp_fit_svd: K, its eigen-decomposition, K^+, H K^+ r and K** - H K^+ H' stay in HBM).  With a
+        communicator every rank serves its own objects and the O(M) results are gathered."""
         kp = _kparams(self._dim, hyp, nugget)
         kss_noise = float(nugget) ** 2
         hyp = np.array(hyp, dtype=np.float64)
-        covs = [None] * self.N_sn
-        for sn in range(self.N_sn):
+        covs = {}
+        pred = [None] * self.N_sn
+        variance = [None] * self.N_sn
+        for sn in self._my_objects():
             new_y0 = self._new_y0(sn)
             self.warning_pf = new_y0
             grid = self._grid(sn)
             cgrid = self.new_binning[sn] if self.as_the_same_time else self.new_binning
             same = grid is cgrid or np.array_equal(grid, cgrid)
             _, _, _, mu, var, cov = self._fit_single_svd(sn, kp, grid, new_y0, kss_noise, want_cov=COV and same)
-            self.Prediction[sn] = mu
-            if COV and not same:
+            pred[sn] = mu
+            if not same:
                 # REFERENCE_STALE_INDEX: the mean uses the stale grid, the covariance the object's own (:351-354)
-                _, _, _, _, var, cov = self._fit_single_svd(sn, kp, cgrid, None, kss_noise, want_cov=True)
-            if COV:
+                _, _, _, _, var, cov = self._fit_single_svd(sn, kp, cgrid, None, kss_noise, want_cov=COV)
+            if cov is not None:
                 covs[sn] = cov
-                self.variance[sn] = var
-        if COV:
-            self.covariance_matrix = covs
+            variance[sn] = var
+        if self.comm is not None:
+            pred = self.comm.gather_unit_arrays(pred, self.N_sn)
+            variance = self.comm.gather_unit_arrays(variance, self.N_sn)
+        self.Prediction = pred
+        self.variance = variance
+        self._cov_state = ('svd', kp, nugget, kss_noise, covs)
 
         def make_inv(sn):
             return svd_inverse(self.kernel(self.Time[sn], hyp, nugget=nugget, y_err=self.y_err[sn], device=self.device),

@@ -110,7 +110,7 @@ class build_pull(object):
         kss_noise = 0. ** 2 + 0. ** 2 + self.nugget ** 2
         for np_ in sorted(subs, reverse=True):
             members = subs[np_]
-            per = max(1, int(gpm.BATCH_BYTES_LIMIT // ((np_ + 128) * np_ * 8)))
+            per = max(1, min(gpm.MAX_BATCH_OBJECTS, int(gpm.BATCH_BYTES_LIMIT // ((np_ + 128) * np_ * 8))))
             for lo in range(0, len(members), per):
                 part = members[lo:lo + per]
                 if any(len(p[3]) == 0 for p in part):

@@ -180,6 +180,31 @@ int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t*
 int cgp_sweep_loglik(cgp_handle* h, int64_t np, const double* kp, const double* diag,
                      double* loglik, int32_t* info);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------
+ * The units of this path (objects of Gaussian_process.py:207-211 / :304-335, hyper-parameter candidates of a
+ * sweep) are independent: every rank fits its own contiguous block on its own GPU, nothing is exchanged while
+ * fitting, and ONE ncclAllGather of the per-unit results ends the call.  The communicator belongs to the
+ * handle and runs on the handle's stream; librccl.so.1 is opened on first use (the single-GPU path never
+ * loads it).  Bootstrap: rank 0 calls cgp_comm_unique_id and hands the 128 bytes to the other ranks by any
+ * out-of-band channel (cosmogp_amd/multigpu.py uses a file or a TCP socket on 127.0.0.1), then every rank
+ * calls cgp_comm_init. */
+#define CGP_COMM_ID_BYTES 128
+enum { CGP_OP_SUM = 0, CGP_OP_MAX = 1 };
+int cgp_comm_unique_id(void* id_out);                                  /* CGP_COMM_ID_BYTES bytes */
+int cgp_comm_init(cgp_handle* h, int rank, int world, const void* id); /* collective over all ranks */
+int cgp_comm_destroy(cgp_handle* h);
+/* recv[world][count] <- send[count] of every rank (host pointers, staged through HBM, ncclAllGather) */
+int cgp_comm_allgather(cgp_handle* h, const double* send, int64_t count, double* recv);
+/* buf[count] <- elementwise sum / max over ranks (ncclAllReduce); count = 0 is a barrier */
+int cgp_comm_allreduce(cgp_handle* h, double* buf, int64_t count, int op);
+/* cgp_sweep_loglik over the ranks of the communicator (BASELINE config[4]): kp[np_total][7] is the FULL
+ * candidate table on every rank; rank r evaluates the contiguous block [lo_r, hi_r) (sizes differ by at most
+ * one) in lock-step launch sequences of at most `chunk` candidates and the log-likelihoods / info words are
+ * gathered device to device (no host hop before the collective): loglik[np_total], info[np_total] complete
+ * on every rank.  The object must be resident on every rank (cgp_fit_set_data). */
+int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, const double* diag,
+                             int64_t chunk, double* loglik, int32_t* info);
+
 /* ---- measurement hooks (bench.py / tests only) ------------------------------------- */
 
 /* Device-resident timing of the last cgp_fit / cgp_batch_fit: runs `iters` fits (or batches) back to back with

@@ -120,3 +120,21 @@ def test_empty_inputs_need_no_device():
     assert cosmogp_amd.rbf_kernel_2d(np.zeros((0, 2)), [1., 1., 1., 0.]).shape == (0, 0)
     assert orc.rbf_kernel_1d(x, [1., 1.]).shape == (0, 0)
     assert orc.rbf_kernel_1d(np.linspace(0, 1, 5), [1., 1.], new_x=x).shape == (0, 5)
+
+
+def test_batch_chunks_respect_grid_and_memory_limits(monkeypatch):
+    """Batched launch sequences carry the object index in gridDim.z (<= 65535) and allocate
+    (Np + round_up(m + 1, 128)) x Np doubles per object: both bound the chunk size."""
+    import cosmogp_amd
+    import importlib
+    gpm = importlib.import_module('cosmogp_amd.gaussian_process')
+    from fake_device import FakeDevice
+    ys = [np.zeros(5)] * 70000
+    xs = [np.arange(5.)] * 70000
+    gp = cosmogp_amd.gaussian_process_nobject(ys, xs, kernel='RBF1D', device=FakeDevice())
+    chunks = gp._batch_chunks(list(range(70000)))
+    assert max(len(c) for c in chunks) <= gpm.MAX_BATCH_OBJECTS and sum(len(c) for c in chunks) == 70000
+    monkeypatch.setattr(gpm, 'BATCH_BYTES_LIMIT', 10 * (128 + 1024) * 128 * 8)
+    small = gp._batch_chunks(list(range(100)), m=1000)          # 1001 -> 1024 tall rows per object
+    assert max(len(c) for c in small) == 10
+    assert max(len(c) for c in gp._batch_chunks(list(range(100)), m=0)) == 45

@@ -30,10 +30,13 @@ def _worker(rank, world, port, out_dir):
     import cosmogp_amd
     from cosmogp_amd import multigpu
     from fake_device import FakeDevice
+    from gloo_comm import GlooComm
     from conftest import load_golden
 
-    comm = multigpu.Comm()
+    comm = GlooComm()
     assert comm.world == world and comm.rank == rank
+    assert comm.agree_any(rank == 1) and not comm.agree_any(False)
+    assert comm.allreduce_max(float(rank)) == world - 1
     # raw gathers
     n_units = 5
     mine = comm.my_units(n_units)
@@ -91,6 +94,40 @@ def _worker(rank, world, port, out_dir):
     # one lock-step launch sequence per rank for its block of candidates, data uploaded once
     assert gp1.device.calls.count('set_data') == 1
     assert gp1.device.calls.count('sweep_loglik:%d' % len(comm.my_units(5))) == 1
+    # a non-positive-definite object on ONE rank: every rank must leave the Cholesky route together (no rank may
+    # sit in a gather its peer never enters) -- raise everywhere with svd_method=False ...
+    xs2 = [np.linspace(0., 1., 6), np.linspace(0., 1., 7), np.linspace(0., 1., 5), np.linspace(0., 1., 8)]
+    ys2 = [np.sin(3. * x) for x in xs2]
+    es2 = [np.full(len(x), 0.1) for x in xs2]
+    es2[3] = np.zeros(8)
+    xs2[3] = np.array([0., 0., 0.2, 0.3, 0.5, 0.6, 0.8, 1.])        # duplicate point, no noise: singular K on rank 1
+    gpb = cosmogp_amd.gaussian_process_nobject(ys2, xs2, kernel='RBF1D', y_err=es2, device=FakeDevice())
+    gpb.comm = comm
+    gpb.hyperparameters = np.array([1., 0.5])
+    raised = False
+    try:
+        gpb.get_prediction(new_binning=np.linspace(0., 1., 4), svd_method=False)
+    except np.linalg.LinAlgError:
+        raised = True
+    assert raised
+    raised = False
+    try:
+        gpb.compute_log_likelihood(np.array([1., 0.5]), svd_method=False)
+    except np.linalg.LinAlgError:
+        raised = True
+    assert raised
+    # ... and fall back to the eigensolver route together with svd_method=True (forced through Cholesky first)
+    import importlib
+    gpm = importlib.import_module('cosmogp_amd.gaussian_process')
+    gpm.SVD_VIA_CHOLESKY_WHEN_PD = True
+    gpb.get_prediction(new_binning=np.linspace(0., 1., 4), svd_method=True)
+    assert all(p is not None and len(p) == 4 for p in gpb.Prediction)
+    ser = cosmogp_amd.gaussian_process_nobject(ys2, xs2, kernel='RBF1D', y_err=es2, device=FakeDevice())
+    ser.hyperparameters = np.array([1., 0.5])
+    ser.get_prediction(new_binning=np.linspace(0., 1., 4), svd_method=True)
+    for i in range(4):
+        np.testing.assert_allclose(gpb.Prediction[i], ser.Prediction[i], rtol=0, atol=1e-6)
+    gpm.SVD_VIA_CHOLESKY_WHEN_PD = 'auto'
     comm.barrier()
     open(os.path.join(out_dir, 'ok_%d' % rank), 'w').write('ok')
     dist.destroy_process_group()
