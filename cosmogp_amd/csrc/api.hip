@@ -2,6 +2,7 @@
 // blocked Cholesky.  gfx950 only.  No torch, no BLAS: every kernel is in kernels.hpp.
 #include "kernels.hpp"
 #include "jacobi.hpp"
+#include "dag.hpp"
 #include "../../include/cosmogp_hip.h"
 
 #include <algorithm>
@@ -76,7 +77,7 @@ struct Prob {
     long rend(long Rfull, long c_end) const { return tri_base >= 0 ? std::min(Rfull, tri_base + c_end) : Rfull; }
 };
 
-enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_GEMM_BIG = 8, ST_COUNT = 12 };
+enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_GEMM_BIG = 8, ST_DAG = 11, ST_COUNT = 12 };
 
 }  // namespace
 
@@ -84,7 +85,8 @@ enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_G
 struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
+    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 1;
     void read() {
         auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
         bulk_cap = (int)num("CGP_BULK_CAP", 0);
@@ -97,6 +99,11 @@ struct CgpEnv {
         stream2 = getenv("CGP_STREAM2") != nullptr;
         debug = getenv("CGP_DEBUG") != nullptr;
         jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
+        no_dag = getenv("CGP_NO_DAG") != nullptr;
+        dag_min_nb = num("CGP_DAG_MIN_NB", 2);
+        dag_timeout_ms = num("CGP_DAG_TIMEOUT_MS", 4000);
+        dag_grid = num("CGP_DAG_GRID", 0);
+        dag_depth = num("CGP_DAG_DEPTH", 1);
     }
 };
 
@@ -111,6 +118,11 @@ struct cgp_handle {
     // cgp_fit_fetch re-upload them, other entry points may have overwritten the shared slot meanwhile
     KParams fit_kp;
     bool have_fit_kp = false;
+    // single-launch factorisation (dag.hpp): task list of the current tile shape, counters, number of CUs
+    DevBuf dtasks, dstate;
+    long dag_nb = -1, dag_nr = -1, dag_depth_built = -1;
+    int dag_ntasks = 0, dag_cus = 0;
+    bool dag_ran = false;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
     std::vector<hipEvent_t> fork_events;
@@ -533,7 +545,7 @@ int cgp_destroy(cgp_handle* h) {
     (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf* all[] = {&h->csend, &h->crecv, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
+    DevBuf* all[] = {&h->csend, &h->crecv, &h->dtasks, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
@@ -640,6 +652,102 @@ int put_resid_row(cgp_handle* h, Prob& P) {
     return 0;
 }
 
+
+// ---- single-launch factorisation (dag.hpp) --------------------------------------------------------------------
+// Task list of the right-looking tile factorisation, in an order every dependency of which points backwards:
+// step k = [TRSM(i, k), i = k+2 .. nr-1] then the updates that panel k feeds.  depth = 1: UPD(i, j, k, k+1) for every
+// tile right of the panel.  depth = d > 1: a tile column j more than `d` panels away collects d panels per update
+// (fewer, deeper read-modify-writes of C: UPD(i, j, k-d+1, k+1) issued at step k when k+1 is a multiple of d), the d
+// columns next to the panel are kept current panel by panel -- they feed the leaf lane within a few steps.
+bool dag_eligible(cgp_handle* h, const Prob& P) {
+    return !h->env.no_dag && P.B == 1 && P.tri_base < 0 && P.wrow0 < 0 && P.Np / NB >= h->env.dag_min_nb && P.R % NB == 0 &&
+           P.Np <= 65536;
+}
+
+int dag_build(cgp_handle* h, long nb, long nr) {
+    const long depth = std::max<long>(1, h->env.dag_depth);
+    if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == depth) return 0;
+    std::vector<int4> t;
+    t.reserve((size_t)(nb * nb * nr / 4 + nr * nb));
+    // applied[j]: panels already scheduled onto tile column j (same for every row of the column)
+    std::vector<long> applied(nb, 0);
+    for (long k = 0; k < nb; ++k) {
+        for (long i = k + 2; i < nr; ++i) t.push_back(make_int4((int)i, (int)k, 0, 0));
+        for (long j = k + 1; j < nb; ++j) {
+            long k0 = -1, k1 = k + 1;
+            if (depth == 1 || j - k <= depth) {
+                k0 = applied[j];                           // near column: bring it up to date with everything finished
+            } else if ((k + 1) % depth == 0) {
+                k0 = applied[j];                           // far column: a full group of `depth` panels has finished
+            }
+            if (k0 < 0 || k0 >= k1) continue;
+            for (long i = j; i < nr; ++i) {
+                if (i == j && j == k + 1 && k1 - k0 == 1) continue;          // the leaf lane applies panel k to tile (k+1, k+1)
+                long a = k0, b = k1;
+                if (i == j && j == k + 1) b = k;                             // ... so the workers stop one panel short there
+                if (b > a) t.push_back(make_int4((int)i, (int)j, (int)a, (int)((b << 1) | 1)));
+            }
+            applied[j] = k1;
+        }
+    }
+    CHK(ensure(h, h->dtasks, t.size() * sizeof(int4)));
+    HIPCHK(hipMemcpyAsync(h->dtasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t words = 8 + (size_t)nr * nb;
+    CHK(ensure(h, h->dstate, (words * sizeof(unsigned) + 15) / 16 * 16));
+    h->dag_ntasks = (int)t.size();
+    h->dag_nb = nb; h->dag_nr = nr; h->dag_depth_built = depth;
+    if (!h->dag_cus) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->device));
+        h->dag_cus = prop.multiProcessorCount;
+    }
+    if (h->env.debug) fprintf(stderr, "cgp: dag task list nb=%ld nr=%ld depth=%ld: %d tasks\n", nb, nr, depth, h->dag_ntasks);
+    return 0;
+}
+
+int launch_dag(cgp_handle* h, Prob& P) {
+    const long nb = P.Np / NB, nr = P.R / NB;
+    // (the list is built outside graph capture: device_fit calls dag_build before it starts capturing)
+    static std::once_flag once_dev[64];
+    static hipError_t err_dev[64];
+    const int d = h->device & 63;
+    std::call_once(once_dev[d], [d]() {
+        err_dev[d] = hipFuncSetAttribute((const void*)k_chol_dag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES);
+    });
+    HIPCHK(err_dev[d]);
+    StageScope sc(h, ST_DAG);
+    const size_t words = 8 + (size_t)nr * nb;
+    HIPCHK(hipMemsetAsync(h->dstate.p, 0, (words * sizeof(unsigned) + 15) / 16 * 16, h->stream));
+    DagParams dp;
+    dp.M = P.M; dp.ld = P.Np; dp.nb = (int)nb; dp.nr = (int)nr;
+    dp.tasks = (const int4*)h->dtasks.p; dp.ntasks = h->dag_ntasks;
+    dp.ctrl = (unsigned*)h->dstate.p; dp.state = (unsigned*)h->dstate.p + 8;
+    dp.wsW = P.wsW; dp.ldp = P.ldp; dp.info = P.info;
+    dp.timeout = (long long)h->env.dag_timeout_ms * 100000ll;           // wall_clock64 runs at 100 MHz
+    dp.dbg = 0;
+    const int grid = h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus;
+    hipLaunchKernelGGL(k_chol_dag, dim3((unsigned)std::max(2, grid)), dim3(DAG_THREADS), DAG_LDS_BYTES, h->stream, dp);
+    HIPCHK(hipGetLastError());
+    h->dag_ran = true;
+    return 0;
+}
+
+// after a synchronised fit: did the single-launch factorisation give up (bounded spins)?
+int dag_check(cgp_handle* h) {
+    if (!h->dag_ran) return 0;
+    h->dag_ran = false;
+    unsigned c[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(c, h->dstate.p, sizeof(c), hipMemcpyDeviceToHost));
+    if (c[1] != 0) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "single-launch factorisation gave up (abort %u, wait code 0x%x, ticket %u of %d, leaf stamp %u)",
+                 c[1], c[2], c[0], h->dag_ntasks, c[3]);
+        return fail(h, CGP_E_HIP, msg);
+    }
+    return 0;
+}
+
 int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
     // device-only part of a fit: everything already in HBM (cgp_fit, cgp_batch_fit, cgp_bench_fit)
     const long ld = P.Np, Mp = P.R - P.Np;
@@ -663,7 +771,8 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         HIPCHK(hipEventRecord(e0, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
     }
-    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    if (dag_eligible(h, P) && !h->trk.active) CHK(launch_dag(h, P));
+    else CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
     if (h->trk.active) {
         // join: everything the second stream did must be complete before the finish kernel (and the
         // capture can only end once every forked stream has been joined)
@@ -680,6 +789,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
 // call instead of 200.  Everything that changes between calls (kernel parameters, kss_noise,
 // diagonal, coordinates) lives in HBM buffers the graph only points to.
 int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
+    if (dag_eligible(h, P)) CHK(dag_build(h, P.Np / NB, P.R / NB));     // (not capturable: host copy + synchronise)
     if (!h->use_graph || h->profiling || h->env.no_graph) return device_fit_eager(h, P, m, has_mean);
     cgp_handle::GraphKey key;
     std::memset(&key, 0, sizeof(key));
@@ -822,6 +932,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
         if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(dag_check(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
@@ -1367,6 +1478,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
                                     hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(dag_check(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1653,6 +1765,7 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
     *ms_per_fit = (double)ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    CHK(dag_check(h));
     if (stage_ms) {
         for (int i = 0; i < 12; ++i) stage_ms[i] = 0.;
         h->profiling = true;
@@ -1703,6 +1816,7 @@ int cgp_bench_fit_objects(cgp_handle* h, int iters, int64_t nobj, double* ms_per
     *ms_per_pass = (double)ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    CHK(dag_check(h));
     return CGP_OK;
 }
 

@@ -1,0 +1,560 @@
+// Single-launch blocked Cholesky of ONE object (gfx950): a persistent grid, one 512-thread workgroup per CU, that walks
+// the tile DAG of the right-looking factorisation with dependency counters in HBM instead of kernel boundaries.
+//
+//   tiles           128 x 128 (CGP_NB); row tiles i = 0 .. nr-1 (the tall rows of the fit included), column tiles
+//                   ("panels") k = 0 .. nb-1
+//   leaf lane       workgroup 0 only.  For k = 0, 1, ...: factor the diagonal tile (k, k) in LDS (potrf128_lds, the K3
+//                   code), solve the tile below it, X = A(k+1, k) L_kk^-T, with the factor still in LDS (the K4 code),
+//                   and apply X X^T to the next diagonal tile, again in LDS: the critical chain of the factorisation never
+//                   leaves this CU and never waits for a launch.
+//   worker lanes    workgroups 1 .. G-1 take tasks from ONE list in ticket order (a device-scope atomic):
+//                     TRSM(i, k)          X = A(i, k) L_kk^-T                         for i >= k + 2
+//                     UPD(i, j, k0, k1)   A(i, j) -= sum_{k0 <= k < k1} L(i, k) L(j, k)^T
+//                   Every dependency of a task sits EARLIER in the list (or on the leaf lane, whose own dependencies sit
+//                   earlier still), and a workgroup only takes a ticket once it is resident: whatever the dispatch order
+//                   or the number of resident workgroups, the first unfinished task always has an owner that can run, so
+//                   the spins below cannot deadlock.  They are bounded anyway (wall-clock limit -> abort word -> every
+//                   lane leaves), so a broken invariant shows as an error code, never as a hang.
+//   state[i][j]     number of panels applied to tile (i, j); the final operation of the tile (factor / solve) makes it
+//                   j + 1.  One writer at a time by construction (updates of a tile are totally ordered by k).
+//
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; one workgroup per CU): every byte another workgroup
+// reads later is stored write-through (`sc1`, 16-byte buffer stores), every storing wave drains (`s_waitcnt vmcnt(0)`),
+// the workgroup's barrier, then ONE lane stores the counter (agent-scope relaxed atomic = `sc1`); the consumer polls that
+// word with `sc1` loads from one wave, its barrier, and EVERY load of handed-off bytes is an `sc1` buffer load to
+// registers (L1 bypassed, so no acquire fence).  No tile is ever read by a workgroup other than its current writer before
+// its final value is published, so no stale copy can exist in another XCD's L2 either.
+#pragma once
+#include "kernels.hpp"
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+struct DagParams {
+    double* M;              // the fit's matrix buffer (rows [0, Np): K -> L, rows [Np, R): tall rows)
+    long ld;                // leading dimension = Np
+    int nb, nr;             // column tiles, row tiles
+    const int4* tasks;      // {i, j, k0, (k1 << 1) | type}   type 0 = TRSM (panel j), 1 = UPD
+    int ntasks;
+    unsigned* state;        // [nr * nb]
+    unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)
+    double* wsW;            // [nb][8][256] T^-T blocks of the diagonal tiles (also read by later solves)
+    double* ldp;            // [nb] logdet parts
+    int* info;
+    long long timeout;      // wall_clock64 ticks (100 MHz) a single wait may last
+    int dbg;                // diagnostics (tools/dag_probe.hip): 0 = run; 1..3 = the leaf lane stops after its initial load /
+                            // first factorisation / first write-back and the workers leave at once; 4 = workers leave at once
+};
+
+#define DAG_THREADS 512
+#define DAG_LDS_DOUBLES (CGP_NB * CGP_LDA + 8 * 256 + 160)
+#define DAG_LDS_BYTES (DAG_LDS_DOUBLES * 8 + 128)      // + control words
+
+enum { DAG_ABORT_TIMEOUT = 1 };
+
+// buffer resource over [base, base + 4 GB); the base is made wave-uniform explicitly (it always is: tile coordinates come
+// from kernel arguments, loop counters and broadcast task descriptors) so that no waterfall loop is generated
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dag_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0xffffffffu, 0x00020000);
+}
+// 16-byte / 8-byte loads and stores that bypass this CU's L1 and write through the XCD's L2 (aux 16 = sc1)
+__device__ __forceinline__ d2 ldc2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16));
+}
+__device__ __forceinline__ void stc2(__amdgpu_buffer_rsrc_t r, unsigned off, d2 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, off, 0, 16);
+}
+__device__ __forceinline__ double ldc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16));
+}
+// every shared word is a GLOBAL (never flat) agent-scope access
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ unsigned dag_ld_flag(const unsigned* p) {
+    return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dag_st_flag(unsigned* p, unsigned v) {
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// progress stamp of the leaf lane (diagnostics after a give-up): ctrl[3]
+__device__ __forceinline__ void dag_stamp(const unsigned* ctrl, unsigned v) {
+    if (threadIdx.x == 0) dag_st_flag((unsigned*)ctrl + 3, v);
+}
+
+// Every thread of the workgroup calls this.  Wave 0 polls up to three counters (lane l polls word l) until each is
+// >= its expected value; the result travels through an LDS word and the workgroup barrier.  false: aborted.
+__device__ __forceinline__ bool dag_wait_impl(const unsigned* ctrl, long long timeout, int nw, const unsigned* w0, unsigned e0,
+                                         const unsigned* w1, unsigned e1, const unsigned* w2, unsigned e2, int code) {
+    extern __shared__ __attribute__((aligned(16))) double smem_w[];
+    int* okword = (int*)(smem_w + DAG_LDS_DOUBLES);
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const unsigned* w = tid == 0 ? w0 : (tid == 1 ? w1 : w2);
+        const unsigned e = tid == 0 ? e0 : (tid == 1 ? e1 : e2);
+        const bool active = tid < nw;
+        int ok = 1;
+        long long t0 = 0;
+        for (unsigned spins = 0;; ++spins) {
+            unsigned v = active ? dag_ld_flag(w) : e;
+            if (__all((int)(v >= e))) break;
+            if (spins == 0) t0 = wall_clock64();
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 15) == 15) {
+                unsigned ab = dag_ld_flag(ctrl + 1);
+                if (ab != 0) { ok = 0; break; }
+                if (wall_clock64() - t0 > timeout) {
+                    if (tid == 0) {
+                        unsigned exp0 = 0u, exp1 = 0u;
+                        __hip_atomic_compare_exchange_strong((gu32*)(ctrl + 1), &exp0, (unsigned)DAG_ABORT_TIMEOUT, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_compare_exchange_strong((gu32*)(ctrl + 2), &exp1, (unsigned)code, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        if (tid == 0) *okword = ok;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*okword) != 0;
+}
+
+// The control steps of a lane are CALLS (a few hundred cycles per task): the compiler then neither merges the spin loops
+// and counter stores of different task kinds nor sinks a counter store out of the loop that must publish it (it did both
+// when they were inlined into the ticket loop, and the result hung on the GPU).
+__device__ __noinline__ int dag_wait(const unsigned* ctrl, long long timeout, int nw, const unsigned* w0, unsigned e0,
+                                     const unsigned* w1, unsigned e1, const unsigned* w2, unsigned e2, int code) {
+    return dag_wait_impl(ctrl, timeout, nw, w0, e0, w1, e1, w2, e2, code) ? 1 : 0;
+}
+
+// publish: every wave drains its write-through stores, the barrier, then ONE lane stores the counter
+__device__ __noinline__ void dag_publish(unsigned* word, unsigned value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) dag_st_flag(word, value);
+    asm volatile("" ::: "memory");
+}
+
+// next ticket: one lane adds to the head word and stages the descriptor in LDS (cw[2..5]); returns the ticket, the same in
+// every lane (>= ntasks: the list is exhausted)
+__device__ __noinline__ int dag_fetch(unsigned* ctrl, const int4* tasks, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) double smem_f[];
+    int* cw = (int*)(smem_f + DAG_LDS_DOUBLES);
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add((gu32*)ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cw[1] = (int)t;
+        if (t < (unsigned)ntasks) {
+            const int4 d = tasks[t];
+            cw[2] = d.x; cw[3] = d.y; cw[4] = d.z; cw[5] = d.w;
+        }
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(cw[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// UPD: C (128 x 128 at Cg) -= A (128 x K at Ag) B^T (128 x K at Bg); all three row-major with leading dimension ld.
+// 8 waves as 2 x 4, wave tile 64 x 32, KB = 16 stages double-buffered in LDS through registers like K5 (kernels.hpp).
+// Column slot (J, lp) of a wave's 32 columns stands for column 8 (J >> 1) + 2 lp + (J & 1): a lane's values for J, J + 1 are
+// two adjacent doubles, so the read-modify-write of C moves 16 bytes per lane and 64 contiguous bytes per row.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const double* Bg, long ld, int K) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int TM = 128, TN = 128, WN = 4, KB = 16, KS = KB + 2, CPR = KB / 2;
+    constexpr int MT = 4, NJ = 8, PA = 2, PB = 2, RSTEP = DAG_THREADS / CPR;      // 64 rows per staging pass
+    double* As = smem;                      // [2][TM * KS]
+    double* Bs = smem + 2 * TM * KS;        // [2][TN * KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4, lp = lane & 3, lb = (lane >> 2) & 3;
+    const int srow = tid / CPR, sch = (tid % CPR) * 2;
+    const __amdgpu_buffer_rsrc_t ra_ = dag_rsrc(Ag), rb_ = dag_rsrc(Bg), rc_ = dag_rsrc(Cg);
+    const unsigned ldb = (unsigned)(ld * 8);
+
+    double acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.;
+    // C values of this lane, fetched before the K loop: acc[i][2 jj], acc[i][2 jj + 1] <-> row 64 wm + 16 i + 4 lb + lq,
+    // columns 32 wn + 8 jj + 2 lp + (0, 1)
+    const unsigned coff = (unsigned)(wm * 64 + 4 * lb + lq) * ldb + (unsigned)(wn * 32 + 2 * lp) * 8u;
+    d2 cv[MT][NJ / 2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ / 2; ++jj) cv[i][jj] = ldc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u);
+
+    d2 ra[2][PA], rb[2][PB];
+    const int nk = K / KB;
+    auto gload = [&](auto par, int kt) {
+        constexpr int P = decltype(par)::value;
+        const unsigned k1 = (unsigned)(kt * KB + sch) * 8u;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) ra[P][q] = ldc2(ra_, (unsigned)(srow + RSTEP * q) * ldb + k1);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) rb[P][q] = ldc2(rb_, (unsigned)(srow + RSTEP * q) * ldb + k1);
+    };
+    auto lstore = [&](auto par, int buf) {
+        constexpr int P = decltype(par)::value;
+#pragma unroll
+        for (int q = 0; q < PA; ++q) *(d2*)(&As[buf * TM * KS + (srow + RSTEP * q) * KS + sch]) = ra[P][q];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) *(d2*)(&Bs[buf * TN * KS + (srow + RSTEP * q) * KS + sch]) = rb[P][q];
+    };
+    auto compute = [&](int cur) {
+        d2 fa[MT], fb[NJ];
+#pragma unroll
+        for (int t = 0; t < KB / 8; ++t) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *(const d2*)(&As[cur * TM * KS + (wm * 64 + i * 16 + lr) * KS + 8 * t + 2 * lq]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                fb[j] = *(const d2*)(&Bs[cur * TN * KS + (wn * 32 + 8 * (j >> 1) + 2 * lp + (j & 1)) * KS + 8 * t + 2 * lq]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].x, fb[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].y, fb[j].y, acc[i][j]);
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    gload(P0{}, 0);
+    gload(P1{}, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(P0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        gload(P0{}, min(kt + 2, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        lstore(P1{}, 1);
+        __syncthreads();
+        gload(P1{}, min(kt + 3, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        lstore(P0{}, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ / 2; ++jj) {
+            d2 o;
+            o.x = cv[i][jj].x - acc[i][2 * jj];
+            o.y = cv[i][jj].y - acc[i][2 * jj + 1];
+            stc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u, o);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The K4 solve of 128 rows (8 waves x 16 rows) against a diagonal block whose factor sits in LDS: Ls (strictly lower
+// 16 x 16 tiles, row stride CGP_LDA) and Ws (the eight T^-T blocks).  Rows at Ap-band `rp` (buffer resource of the tile's
+// first row and column), X is stored back write-through and returned in S (K4's register layout: S[jb][0..3] =
+// columns 16 jb + 4 lu + (0..3) of row 16 wave + 4 lb + lq).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dag_trsm_rows(double* Ls, double* Ws, __amdgpu_buffer_rsrc_t rp, unsigned ldb, double (&S)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+    // wave-private 16 x 16 tile in the part of Ls that holds no strictly-lower tile (see k_trsm_panel)
+    const int xg = wave < 6 ? 0 : 1, xt = wave - 6 * xg;
+    double* Xs = Ls + xg * 16 * CGP_LDA + 16 + 18 * xt;
+    const unsigned aoff = (unsigned)(wave * 16 + 4 * lb + lq) * ldb + (unsigned)(4 * lu) * 8u;
+    // S holds the not yet solved column tiles of this wave's rows; a finished X_jb replaces S[jb] in place
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d2 t0 = ldc2(rp, aoff + (unsigned)(jb * 16) * 8u), t1 = ldc2(rp, aoff + (unsigned)(jb * 16 + 2) * 8u);
+        S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        wave_lds_fence();
+        *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu) = (d2){S[jb][0], S[jb][1]};
+        *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu + 2) = (d2){S[jb][2], S[jb][3]};
+        wave_lds_fence();
+        double x[4] = {0., 0., 0., 0.};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            d2 a = *(const d2*)(Xs + lr * CGP_LDA + 8 * t + 2 * lq);
+            const double* w0 = Ws + jb * 256 + (8 * t + 2 * lq) * 16 + 4 * lu;
+            d2 p0 = *(const d2*)(w0), p1 = *(const d2*)(w0 + 2), p2 = *(const d2*)(w0 + 16), p3 = *(const d2*)(w0 + 18);
+            x[0] = mfma4(a.x, p0.x, x[0]); x[1] = mfma4(a.x, p0.y, x[1]);
+            x[2] = mfma4(a.x, p1.x, x[2]); x[3] = mfma4(a.x, p1.y, x[3]);
+            x[0] = mfma4(a.y, p2.x, x[0]); x[1] = mfma4(a.y, p2.y, x[1]);
+            x[2] = mfma4(a.y, p3.x, x[2]); x[3] = mfma4(a.y, p3.y, x[3]);
+        }
+        stc2(rp, aoff + (unsigned)(jb * 16) * 8u, (d2){x[0], x[1]});
+        stc2(rp, aoff + (unsigned)(jb * 16 + 2) * 8u, (d2){x[2], x[3]});
+#pragma unroll
+        for (int J = 0; J < 4; ++J) S[jb][J] = x[J];
+        if (jb < 7) {
+            wave_lds_fence();
+            *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu) = (d2){x[0], x[1]};
+            *(d2*)(Xs + (4 * lb + lq) * CGP_LDA + 4 * lu + 2) = (d2){x[2], x[3]};
+            wave_lds_fence();
+            d2 a[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = -*(const d2*)(Xs + lr * CGP_LDA + 8 * t + 2 * lq);
+#pragma unroll
+            for (int i = jb + 1; i < 8; ++i) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    d2 bb[4];
+#pragma unroll
+                    for (int J = 0; J < 4; ++J)
+                        bb[J] = *(const d2*)(Ls + (i * 16 + 4 * lu + J) * CGP_LDA + jb * 16 + 8 * t + 2 * lq);
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) S[i][J] = mfma4(a[t].x, bb[J].x, S[i][J]);
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) S[i][J] = mfma4(a[t].y, bb[J].y, S[i][J]);
+                }
+            }
+        }
+    }
+}
+
+// worker TRSM(i, k): stage L_kk (rows 16..127 hold strictly-lower tiles) and its T^-T blocks, then solve the tile
+__device__ __noinline__ void dag_trsm_task(double* M, long ld, const double* wsW, int i, int k) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    struct { double* M; long ld; const double* wsW; } p = {M, ld, wsW};
+    double* Ls = smem;
+    double* Ws = smem + CGP_NB * CGP_LDA;
+    const int tid = threadIdx.x;
+    const unsigned ldb = (unsigned)(p.ld * 8);
+    const __amdgpu_buffer_rsrc_t rl = dag_rsrc(p.M + (long)(k * CGP_NB) * p.ld + (long)k * CGP_NB);
+    const __amdgpu_buffer_rsrc_t rw = dag_rsrc(p.wsW + (long)k * (8 * 256));
+    // rows 16..127, columns 0..(row tile start): 112 rows x 64 chunks of 16 B, only chunks left of the diagonal tile
+    constexpr int NCH = 112 * 64 / DAG_THREADS;          // 14
+    d2 v[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int idx = tid + q * DAG_THREADS, r = 16 + (idx >> 6), c = (idx & 63) * 2;
+        v[q] = (c >> 4) < (r >> 4) ? ldc2(rl, (unsigned)r * ldb + (unsigned)c * 8u) : (d2){0., 0.};
+    }
+    d2 w[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) w[q] = ldc2(rw, (unsigned)(tid + q * DAG_THREADS) * 16u);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int idx = tid + q * DAG_THREADS, r = 16 + (idx >> 6), c = (idx & 63) * 2;
+        if ((c >> 4) < (r >> 4)) *(d2*)(Ls + r * CGP_LDA + c) = v[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(d2*)(Ws + 2 * (tid + q * DAG_THREADS)) = w[q];
+    __syncthreads();
+    double xs[8][4];
+    dag_trsm_rows(Ls, Ws, dag_rsrc(p.M + (long)(i * CGP_NB) * p.ld + (long)k * CGP_NB), ldb, xs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// leaf lane
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dag_tile_of(int t, int& ti, int& tj) {      // t-th lower tile of an 8 x 8 tile grid, row-major
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    ti = i;
+    tj = t - i * (i + 1) / 2;
+}
+
+// the K3 factorisation as a CALL: its register allocation (183 VGPRs, a long unrolled pivot chain) stays its own instead of
+// being merged with the solve / update code around it.  The dynamic LDS is addressed through its own symbol, so the
+// accesses stay ds_* instructions.
+__device__ __noinline__ int dag_potrf_call() {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    return potrf128_lds(smem_, smem_ + CGP_NB * CGP_LDA, smem_ + CGP_NB * CGP_LDA + 8 * 256);
+}
+
+// Steps of the leaf lane as CALLS as well: nothing but the step counter lives in registers across them (the diagonal
+// tile and the factor travel through LDS), so the unrolled pivot chain of the factorisation and the solve / update code
+// do not compete for registers.
+//
+// dag_leaf_near(k): solve the tile below the diagonal with the factor of (k, k) still in LDS, publish it, then turn
+// LDS into the next diagonal tile: (k+1, k+1) as the workers left it (panels 0..k-1 applied) minus X X^T.
+// Returns 0 = aborted, 1 = done and the next diagonal tile is in LDS, 2 = done, no further diagonal tile.
+__device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned* state, const unsigned* ctrl, long long timeout, int k) {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    struct { double* M; long ld; int nb; unsigned* state; } p = {M, ld, nb_, state};
+    double* As = smem_;
+    double* Ws = smem_ + CGP_NB * CGP_LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+    const unsigned ldb = (unsigned)(p.ld * 8);
+    const int nb = p.nb;
+
+    if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr, 0, nullptr, 0,
+                                                 0x10000 + k))) return 0;
+    double S[8][4];
+    dag_trsm_rows(As, Ws, dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)k * CGP_NB), ldb, S);
+    dag_publish(p.state + (long)(k + 1) * nb + k, (unsigned)(k + 1));       // barrier inside: every wave is done with L_kk
+    if (k + 1 >= nb) return 2;
+
+    // next diagonal tile (workers have applied panels 0..k-1): this wave's share of its 36 lower 16 x 16 tiles (dealt
+    // round robin over the 8 waves) into registers, X into LDS
+    if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
+                                                 nullptr, 0, 0x20000 + k))) return 0;
+    constexpr int NT = 5;
+    double dacc[NT][4];
+    int tti[NT], ttj[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int a = 0, b = 0;
+        dag_tile_of(min(wave + 8 * n, 35), a, b);
+        tti[n] = __builtin_amdgcn_readfirstlane(a);
+        ttj[n] = __builtin_amdgcn_readfirstlane(b);
+    }
+    const __amdgpu_buffer_rsrc_t rn = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)(k + 1) * CGP_NB);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        if (wave + 8 * n < 36) {
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+                dacc[n][J] = ldc1(rn, (unsigned)(tti[n] * 16 + 4 * lb + lq) * ldb + (unsigned)(ttj[n] * 16 + lu + 4 * J) * 8u);
+        }
+    }
+    // X rows of this wave (row 16 wave + 4 lb + lq, columns 16 jb + 4 lu + 0..3) -> As
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        double* dst = As + (wave * 16 + 4 * lb + lq) * CGP_LDA + jb * 16 + 4 * lu;
+        *(d2*)(dst) = (d2){S[jb][0], S[jb][1]};
+        *(d2*)(dst + 2) = (d2){S[jb][2], S[jb][3]};
+    }
+    __syncthreads();
+    // tile (k+1, k+1) -= X X^T
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        if (wave + 8 * n < 36) {
+            const int ti = tti[n], tj = ttj[n];
+#pragma unroll 2
+            for (int kc = 0; kc < 8; ++kc)
+                tile_mma_nt<true>(dacc[n], As + (ti * 16) * CGP_LDA + 16 * kc, As + (tj * 16) * CGP_LDA + 16 * kc, lr, lu, lq);
+        }
+    }
+    __syncthreads();                 // every wave has read X
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        if (wave + 8 * n < 36) {
+            const int ti = tti[n], tj = ttj[n];
+#pragma unroll
+            for (int J = 0; J < 4; ++J) As[(ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu + 4 * J] = dacc[n][J];
+        }
+    }
+    __syncthreads();
+    return 1;
+}
+
+// write L_kk (in LDS) and its T^-T blocks back write-through, logdet part, info, then publish the factor
+__device__ __noinline__ void dag_leaf_writeback(double* M, long ld, int nb_, unsigned* state, double* wsW, double* ldp, int* info,
+                                                 int k, int bad) {
+    extern __shared__ __attribute__((aligned(16))) double smem_[];
+    struct { double* M; long ld; int nb; unsigned* state; double* wsW; double* ldp; int* info; } p = {M, ld, nb_, state, wsW, ldp, info};
+    double* As = smem_;
+    double* Ws = smem_ + CGP_NB * CGP_LDA;
+    double* Lc = Ws + 8 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned ldb = (unsigned)(p.ld * 8);
+    const __amdgpu_buffer_rsrc_t rd = dag_rsrc(p.M + (long)(k * CGP_NB) * p.ld + (long)k * CGP_NB);
+    constexpr int NCH = CGP_NB * 64 / DAG_THREADS;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int idx = tid + q * DAG_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+        if ((c >> 4) <= (r >> 4)) stc2(rd, (unsigned)r * ldb + (unsigned)c * 8u, *(const d2*)(As + r * CGP_LDA + c));
+    }
+    const __amdgpu_buffer_rsrc_t rw = dag_rsrc(p.wsW + (long)k * (8 * 256));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) stc2(rw, (unsigned)(tid + q * DAG_THREADS) * 16u, *(const d2*)(Ws + 2 * (tid + q * DAG_THREADS)));
+    double lg = 0.;
+    if (tid < CGP_NB) lg = 2. * log(As[tid * CGP_LDA + tid]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+    double* red = Lc + 128;
+    if (lane == 0 && wave < 2) red[wave] = lg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        p.ldp[k] = red[0] + red[1];
+        if (bad != 0 && p.info[0] == 0) p.info[0] = k * CGP_NB + bad;
+        dag_st_flag(p.state + (long)k * p.nb + k, (unsigned)(k + 1));
+    }
+}
+
+__device__ void dag_leaf(const DagParams& p, double* smem) {
+    double* As = smem;
+    const int tid = threadIdx.x;
+    const unsigned ldb = (unsigned)(p.ld * 8);
+    {
+        // tile (0, 0) as assembled, straight into LDS (tiles on and below the block diagonal)
+        const __amdgpu_buffer_rsrc_t rd = dag_rsrc(p.M);
+        constexpr int NCH = CGP_NB * 64 / DAG_THREADS;      // 16
+        d2 v[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int idx = tid + q * DAG_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            v[q] = (c >> 4) <= (r >> 4) ? ldc2(rd, (unsigned)r * ldb + (unsigned)c * 8u) : (d2){0., 0.};
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int idx = tid + q * DAG_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            if ((c >> 4) <= (r >> 4)) *(d2*)(As + r * CGP_LDA + c) = v[q];
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < p.nb; ++k) {
+        dag_stamp(p.ctrl, 4u * k + 1u);
+        if (p.dbg == 1) return;
+        const int bad = dag_potrf_call();
+        dag_stamp(p.ctrl, 4u * k + 2u);
+        if (p.dbg == 2) return;
+        dag_leaf_writeback(p.M, p.ld, p.nb, p.state, p.wsW, p.ldp, p.info, k, bad);
+        dag_stamp(p.ctrl, 4u * k + 3u);
+        if (p.dbg == 3) return;
+        if (k + 1 >= p.nr) break;
+        if (dag_leaf_near(p.M, p.ld, p.nb, p.state, p.ctrl, p.timeout, k) != 1) break;
+    }
+    dag_stamp(p.ctrl, 0xffffu);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int* cw = (int*)(smem + DAG_LDS_DOUBLES);       // [0] wait result, [1..5] ticket + descriptor
+    if (blockIdx.x == 0) {
+        dag_leaf(p, smem);
+        return;
+    }
+    const int nb = p.nb;
+    if (p.dbg != 0 && p.dbg < 5) return;
+    for (;;) {
+        const int t = __builtin_amdgcn_readfirstlane(dag_fetch(p.ctrl, p.tasks, p.ntasks));
+        if (t >= p.ntasks) break;
+        const int i = __builtin_amdgcn_readfirstlane(cw[2]), j = __builtin_amdgcn_readfirstlane(cw[3]);
+        const int k0 = __builtin_amdgcn_readfirstlane(cw[4]), w = __builtin_amdgcn_readfirstlane(cw[5]);
+        const int type = w & 1, k1 = w >> 1;
+        if (type == 0) {
+            // TRSM(i, k = j): needs the factor of (k, k) and every update of (i, k)
+            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 2, p.state + (long)j * nb + j, (unsigned)(j + 1),
+                                                         p.state + (long)i * nb + j, (unsigned)j, nullptr, 0, 0x30000 + t))) break;
+            if (p.dbg != 5 && p.dbg != 7) dag_trsm_task(p.M, p.ld, p.wsW, i, j);
+            dag_publish(p.state + (long)i * nb + j, (unsigned)(j + 1));
+        } else {
+            // UPD(i, j, k0, k1): panels k0..k1-1 of rows i and j final, tile (i, j) updated through k0-1
+            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 3, p.state + (long)i * nb + (k1 - 1), (unsigned)k1,
+                                                         p.state + (long)j * nb + (k1 - 1), (unsigned)k1, p.state + (long)i * nb + j,
+                                                         (unsigned)k0, 0x40000 + t))) break;
+            if (p.dbg != 5 && p.dbg != 6)
+                dag_upd_tile(p.M + (long)(i * CGP_NB) * p.ld + (long)j * CGP_NB, p.M + (long)(i * CGP_NB) * p.ld + (long)k0 * CGP_NB,
+                             p.M + (long)(j * CGP_NB) * p.ld + (long)k0 * CGP_NB, p.ld, (k1 - k0) * CGP_NB);
+            dag_publish(p.state + (long)i * nb + j, (unsigned)k1);
+        }
+    }
+    if (p.dbg >= 5 && threadIdx.x == 0) dag_st_flag(p.ctrl + 5, 0x4000u);
+}

@@ -290,29 +290,14 @@ __device__ __forceinline__ void tile_mma_nt(double (&acc)[4], const double* Arow
 #define CGP_K3_THREADS 512
 #define CGP_K3_WAVES (CGP_K3_THREADS / 64)
 
-__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
-    double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
-    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem;                          // [128][CGP_LDA]
-    double* Ws = smem + CGP_NB * CGP_LDA;       // [8][16][16]  T^-T blocks (upper triangular)
-    double* Lc = Ws + 8 * 256;                  // [2][64] column broadcast buffer of phase (a)
-    const int b = blockIdx.z;
-    M += (long)b * sM + (long)c0 * ld + c0;
-    wsW += (long)b * sW + (long)blk * (8 * 256);
+// The factorisation proper of a 128 x 128 block that already sits in LDS (As, row stride CGP_LDA; only the tiles on
+// and below the block diagonal are read).  On return As holds L (diagonal tiles lower triangular, zeros above), Ws the
+// eight T^-T blocks.  Called by all CGP_K3_THREADS threads of the workgroup; returns (in wave 0) the 1-based local
+// index of the first non-positive pivot, 0 if none.  Shared by K3 and by the leaf lane of the single-launch
+// factorisation (dag.hpp).
+__device__ __forceinline__ int potrf128_lds(double* As, double* Ws, double* Lc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
-
-    CGP_STAMP(0);
-    // load the block by direct global -> LDS loads: one wave instruction = one full row (128 doubles) into
-    // As[r][0..127]; the part right of the diagonal tile is never read
-    for (int r = wave; r < CGP_NB; r += CGP_K3_THREADS / 64)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(M + (long)r * ld + 2 * lane),
-                                         (__attribute__((address_space(3))) void*)(As + r * CGP_LDA), 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    CGP_STAMP(1);
-
     int bad = 0;   // 1-based local index of the first non-positive pivot (wave 0 only)
     // Schedule of sub-step s (two workgroup barriers; everything that is not on the pivot chain runs
     // under phase (a) of the pivot wave):
@@ -442,6 +427,34 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
         __syncthreads();
         CGP_STAMP(4 + 4 * s);
     }
+
+    return bad;
+}
+
+__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
+    double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
+    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                          // [128][CGP_LDA]
+    double* Ws = smem + CGP_NB * CGP_LDA;       // [8][16][16]  T^-T blocks (upper triangular)
+    double* Lc = Ws + 8 * 256;                  // [2][64] column broadcast buffer of phase (a)
+    const int b = blockIdx.z;
+    M += (long)b * sM + (long)c0 * ld + c0;
+    wsW += (long)b * sW + (long)blk * (8 * 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+
+    CGP_STAMP(0);
+    // load the block by direct global -> LDS loads: one wave instruction = one full row (128 doubles) into
+    // As[r][0..127]; the part right of the diagonal tile is never read
+    for (int r = wave; r < CGP_NB; r += CGP_K3_THREADS / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(M + (long)r * ld + 2 * lane),
+                                         (__attribute__((address_space(3))) void*)(As + r * CGP_LDA), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CGP_STAMP(1);
+
+    const int bad = potrf128_lds(As, Ws, Lc);
 
     CGP_STAMP(40);
     // write L back (tiles on and below the block diagonal), T^-T blocks, logdet, info

@@ -1,0 +1,110 @@
+"""Single-launch factorisation (csrc/dag.hpp): one persistent kernel walks the tile DAG of the blocked Cholesky with
+dependency counters in HBM.  It is the default route of a single-object fit; the launch-per-step route
+(CGP_NO_DAG=1) computes the same tiles with a different association of the sums, so the two agree to rounding
+(tolerances below), each of them is run-to-run bit-reproducible, and both agree with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import cosmogp_oracle as orc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def _problem(n, m, seed, dim=1):
+    rng = np.random.default_rng(seed)
+    if dim == 1:
+        x = np.sort(rng.uniform(0., 0.15 * n, n))
+        xn = rng.uniform(0., 0.15 * n, m) if m else None
+        y = np.sin(0.05 * x) + 0.3 * np.cos(0.31 * x) + 0.1 * rng.standard_normal(n)
+    else:
+        s_ = 24. * np.sqrt(n)
+        x = rng.uniform(0., s_, (n, 2))
+        xn = rng.uniform(0., s_, (m, 2)) if m else None
+        y = np.sin(x[:, 0] / 150.) * np.cos(x[:, 1] / 170.) + 0.1 * rng.standard_normal(n)
+    return x, y, np.full(n, 0.1), xn
+
+
+def _fit(env, monkeypatch, dim, x, y, e, xn, reps=1):
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    for k in ('CGP_NO_DAG', 'CGP_NO_GRAPH', 'CGP_DAG_DEPTH', 'CGP_DAG_GRID', 'CGP_LOOKAHEAD'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = _lib.Device(0)
+    kp = K.kernel_params_1d([1., 2.]) if dim == 1 else K.kernel_params_2d([1., 110., 90., 300.])
+    dev.set_data(dim, x, y)
+    outs = [dev.fit(kp, K.diag_term(len(y), e, 0., 0.), xn, None, 0.) for _ in range(reps)]
+    dev.close()
+    return outs
+
+
+def _close(a, b, tol):
+    assert abs(a[0] - b[0]) <= tol * abs(b[0]) and abs(a[1] - b[1]) <= tol * abs(b[1])
+    if a[2] is not None:
+        np.testing.assert_allclose(a[2], b[2], rtol=0, atol=tol * 100)
+        np.testing.assert_allclose(a[3], b[3], rtol=0, atol=tol * 100)
+
+
+@pytest.mark.parametrize('n,m,dim', [(129, 0, 1), (256, 5, 1), (300, 40, 1), (640, 0, 2), (1000, 333, 1), (2048, 100, 2),
+                                     (3000, 1, 1), (4096, 1024, 1)])
+def test_dag_equals_launch_route_and_oracle(monkeypatch, n, m, dim):
+    x, y, e, xn = _problem(n, m, 100 + n, dim)
+    a = _fit({}, monkeypatch, dim, x, y, e, xn, reps=3)
+    b = _fit({'CGP_NO_DAG': '1'}, monkeypatch, dim, x, y, e, xn)[0]
+    # replaying the captured launch gives the same bits: the sums of every tile have a fixed order whatever the
+    # interleaving of the workgroups
+    for o in a[1:]:
+        assert o[0] == a[0][0] and o[1] == a[0][1]
+        if m:
+            assert np.array_equal(o[2], a[0][2]) and np.array_equal(o[3], a[0][3])
+    _close(a[0], b, 1e-12)
+    if n <= 1000:
+        hyp = [1., 2.] if dim == 1 else [1., 110., 90., 300.]
+        kern = orc.rbf_kernel_1d if dim == 1 else orc.rbf_kernel_2d
+        Kc = kern(x, hyp, y_err=e)
+        if m:
+            mu, var, ll = orc.fit_predict_cho(Kc, y, kern(x, hyp, new_x=xn), np.full(m, 1.))
+            np.testing.assert_allclose(a[0][2], mu, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(a[0][3], var, rtol=0, atol=1e-9)
+        else:
+            ll = orc.log_likelihood_gp(y, x, 'RBF1D' if dim == 1 else 'RBF2D', hyp, 0., y_err=e, svd_method=False)[0]
+        assert abs(a[0][0] - ll) <= 1e-11 * abs(ll)
+
+
+def test_dag_eager_few_workgroups_and_depths(monkeypatch):
+    """Eager launch = captured launch bit for bit; a grid of 3 workgroups (one leaf lane, two workers) and of 17 walk
+    the same list (no assumption on residency or dispatch order); deeper far updates (CGP_DAG_DEPTH) re-associate sums."""
+    x, y, e, xn = _problem(1500, 200, 7)
+    ref = _fit({}, monkeypatch, 1, x, y, e, xn)[0]
+    for env in ({'CGP_NO_GRAPH': '1'}, {'CGP_DAG_GRID': '3'}, {'CGP_DAG_GRID': '17'}):
+        o = _fit(env, monkeypatch, 1, x, y, e, xn)[0]
+        assert o[0] == ref[0] and o[1] == ref[1] and np.array_equal(o[2], ref[2]) and np.array_equal(o[3], ref[3])
+    for depth in ('2', '4'):
+        o = _fit({'CGP_DAG_DEPTH': depth}, monkeypatch, 1, x, y, e, xn)[0]
+        _close(o, ref, 1e-12)
+
+
+def test_dag_not_positive_definite(monkeypatch):
+    """A non-positive pivot is reported like LAPACK's info and nothing hangs (NaNs flow through the counters)."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    monkeypatch.delenv('CGP_NO_DAG', raising=False)
+    x = np.linspace(0., 5., 700)
+    dev = _lib.Device(0)
+    dev.set_data(1, x, np.sin(x))
+    with pytest.raises(np.linalg.LinAlgError):
+        dev.fit(K.kernel_params_1d([1., 2.]), np.zeros(700))
+    # the handle stays usable
+    ll = dev.fit(K.kernel_params_1d([1., 2.]), np.full(700, 0.01))[0]
+    ref = orc.log_likelihood_gp(np.sin(x), x, 'RBF1D', [1., 2.], 0., y_err=np.full(700, 0.1), svd_method=False)[0]
+    assert abs(ll - ref) <= 1e-9 * abs(ref)
+    dev.close()
+
+
+def test_dag_c3_size(monkeypatch):
+    """BASELINE config[2] size through the single launch: equals the launch-per-step route to rounding."""
+    x, y, e, xn = _problem(8192, 2500, 3, dim=2)
+    a = _fit({}, monkeypatch, 2, x, y, e, xn)[0]
+    b = _fit({'CGP_NO_DAG': '1'}, monkeypatch, 2, x, y, e, xn)[0]
+    _close(a, b, 1e-11)
