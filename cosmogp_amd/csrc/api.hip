@@ -3,6 +3,7 @@
 #include "kernels.hpp"
 #include "jacobi.hpp"
 #include "dag.hpp"
+#include "dag_tasks.hpp"
 #include "../../include/cosmogp_hip.h"
 
 #include <algorithm>
@@ -654,11 +655,7 @@ int put_resid_row(cgp_handle* h, Prob& P) {
 
 
 // ---- single-launch factorisation (dag.hpp) --------------------------------------------------------------------
-// Task list of the right-looking tile factorisation, in an order every dependency of which points backwards:
-// step k = [TRSM(i, k), i = k+2 .. nr-1] then the updates that panel k feeds.  depth = 1: UPD(i, j, k, k+1) for every
-// tile right of the panel.  depth = d > 1: a tile column j more than `d` panels away collects d panels per update
-// (fewer, deeper read-modify-writes of C: UPD(i, j, k-d+1, k+1) issued at step k when k+1 is a multiple of d), the d
-// columns next to the panel are kept current panel by panel -- they feed the leaf lane within a few steps.
+// (task list: dag_tasks.hpp)
 bool dag_eligible(cgp_handle* h, const Prob& P) {
     return !h->env.no_dag && P.B == 1 && P.tri_base < 0 && P.wrow0 < 0 && P.Np / NB >= h->env.dag_min_nb && P.R % NB == 0 &&
            P.Np <= 65536;
@@ -668,28 +665,7 @@ int dag_build(cgp_handle* h, long nb, long nr) {
     const long depth = std::max<long>(1, h->env.dag_depth);
     if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == depth) return 0;
     std::vector<int4> t;
-    t.reserve((size_t)(nb * nb * nr / 4 + nr * nb));
-    // applied[j]: panels already scheduled onto tile column j (same for every row of the column)
-    std::vector<long> applied(nb, 0);
-    for (long k = 0; k < nb; ++k) {
-        for (long i = k + 2; i < nr; ++i) t.push_back(make_int4((int)i, (int)k, 0, 0));
-        for (long j = k + 1; j < nb; ++j) {
-            long k0 = -1, k1 = k + 1;
-            if (depth == 1 || j - k <= depth) {
-                k0 = applied[j];                           // near column: bring it up to date with everything finished
-            } else if ((k + 1) % depth == 0) {
-                k0 = applied[j];                           // far column: a full group of `depth` panels has finished
-            }
-            if (k0 < 0 || k0 >= k1) continue;
-            for (long i = j; i < nr; ++i) {
-                if (i == j && j == k + 1 && k1 - k0 == 1) continue;          // the leaf lane applies panel k to tile (k+1, k+1)
-                long a = k0, b = k1;
-                if (i == j && j == k + 1) b = k;                             // ... so the workers stop one panel short there
-                if (b > a) t.push_back(make_int4((int)i, (int)j, (int)a, (int)((b << 1) | 1)));
-            }
-            applied[j] = k1;
-        }
-    }
+    dag_build_tasks(nb, nr, depth, t);
     CHK(ensure(h, h->dtasks, t.size() * sizeof(int4)));
     HIPCHK(hipMemcpyAsync(h->dtasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -726,6 +702,7 @@ int launch_dag(cgp_handle* h, Prob& P) {
     dp.wsW = P.wsW; dp.ldp = P.ldp; dp.info = P.info;
     dp.timeout = (long long)h->env.dag_timeout_ms * 100000ll;           // wall_clock64 runs at 100 MHz
     dp.dbg = 0;
+    dp.prof = nullptr;
     const int grid = h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus;
     hipLaunchKernelGGL(k_chol_dag, dim3((unsigned)std::max(2, grid)), dim3(DAG_THREADS), DAG_LDS_BYTES, h->stream, dp);
     HIPCHK(hipGetLastError());

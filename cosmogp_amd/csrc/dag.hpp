@@ -42,6 +42,8 @@ struct DagParams {
     double* ldp;            // [nb] logdet parts
     int* info;
     long long timeout;      // wall_clock64 ticks (100 MHz) a single wait may last
+    unsigned long long* prof;   // diagnostics (tools/dag_probe.hip), may be null: [k][8] leaf-lane time stamps (100 MHz), then
+                                // per worker [G][4] ticks spent waiting / in TRSM / in UPD, tasks run
     int dbg;                // diagnostics (tools/dag_probe.hip): 0 = run; 1..3 = the leaf lane stops after its initial load /
                             // first factorisation / first write-back and the workers leave at once; 4 = workers leave at once
 };
@@ -379,7 +381,8 @@ __device__ __noinline__ int dag_potrf_call() {
 // dag_leaf_near(k): solve the tile below the diagonal with the factor of (k, k) still in LDS, publish it, then turn
 // LDS into the next diagonal tile: (k+1, k+1) as the workers left it (panels 0..k-1 applied) minus X X^T.
 // Returns 0 = aborted, 1 = done and the next diagonal tile is in LDS, 2 = done, no further diagonal tile.
-__device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned* state, const unsigned* ctrl, long long timeout, int k) {
+__device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned* state, const unsigned* ctrl, long long timeout, int k,
+                                          unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
     struct { double* M; long ld; int nb; unsigned* state; } p = {M, ld, nb_, state};
     double* As = smem_;
@@ -391,15 +394,18 @@ __device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned*
 
     if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr, 0, nullptr, 0,
                                                  0x10000 + k))) return 0;
+    if (prof && tid == 0) prof[0] = wall_clock64();
     double S[8][4];
     dag_trsm_rows(As, Ws, dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)k * CGP_NB), ldb, S);
     dag_publish(p.state + (long)(k + 1) * nb + k, (unsigned)(k + 1));       // barrier inside: every wave is done with L_kk
+    if (prof && tid == 0) prof[1] = wall_clock64();
     if (k + 1 >= nb) return 2;
 
     // next diagonal tile (workers have applied panels 0..k-1): this wave's share of its 36 lower 16 x 16 tiles (dealt
     // round robin over the 8 waves) into registers, X into LDS
     if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
                                                  nullptr, 0, 0x20000 + k))) return 0;
+    if (prof && tid == 0) prof[2] = wall_clock64();
     constexpr int NT = 5;
     double dacc[NT][4];
     int tti[NT], ttj[NT];
@@ -447,6 +453,7 @@ __device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned*
         }
     }
     __syncthreads();
+    if (prof && tid == 0) prof[3] = wall_clock64();
     return 1;
 }
 
@@ -509,14 +516,17 @@ __device__ void dag_leaf(const DagParams& p, double* smem) {
     for (int k = 0; k < p.nb; ++k) {
         dag_stamp(p.ctrl, 4u * k + 1u);
         if (p.dbg == 1) return;
+        if (p.prof && tid == 0) p.prof[k * 8 + 0] = wall_clock64();
         const int bad = dag_potrf_call();
+        if (p.prof && tid == 0) p.prof[k * 8 + 1] = wall_clock64();
         dag_stamp(p.ctrl, 4u * k + 2u);
         if (p.dbg == 2) return;
         dag_leaf_writeback(p.M, p.ld, p.nb, p.state, p.wsW, p.ldp, p.info, k, bad);
+        if (p.prof && tid == 0) p.prof[k * 8 + 2] = wall_clock64();
         dag_stamp(p.ctrl, 4u * k + 3u);
         if (p.dbg == 3) return;
         if (k + 1 >= p.nr) break;
-        if (dag_leaf_near(p.M, p.ld, p.nb, p.state, p.ctrl, p.timeout, k) != 1) break;
+        if (dag_leaf_near(p.M, p.ld, p.nb, p.state, p.ctrl, p.timeout, k, p.prof ? p.prof + k * 8 + 3 : nullptr) != 1) break;
     }
     dag_stamp(p.ctrl, 0xffffu);
 }
@@ -533,7 +543,9 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
     }
     const int nb = p.nb;
     if (p.dbg != 0 && p.dbg < 5) return;
+    long long acc_wait = 0, acc_trsm = 0, acc_upd = 0, acc_n = 0, tm0 = 0, tm1 = 0;
     for (;;) {
+        if (p.prof) tm0 = wall_clock64();
         const int t = __builtin_amdgcn_readfirstlane(dag_fetch(p.ctrl, p.tasks, p.ntasks));
         if (t >= p.ntasks) break;
         const int i = __builtin_amdgcn_readfirstlane(cw[2]), j = __builtin_amdgcn_readfirstlane(cw[3]);
@@ -543,18 +555,26 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
             // TRSM(i, k = j): needs the factor of (k, k) and every update of (i, k)
             if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 2, p.state + (long)j * nb + j, (unsigned)(j + 1),
                                                          p.state + (long)i * nb + j, (unsigned)j, nullptr, 0, 0x30000 + t))) break;
+            if (p.prof) tm1 = wall_clock64();
             if (p.dbg != 5 && p.dbg != 7) dag_trsm_task(p.M, p.ld, p.wsW, i, j);
             dag_publish(p.state + (long)i * nb + j, (unsigned)(j + 1));
+            if (p.prof) { acc_wait += tm1 - tm0; acc_trsm += wall_clock64() - tm1; ++acc_n; }
         } else {
             // UPD(i, j, k0, k1): panels k0..k1-1 of rows i and j final, tile (i, j) updated through k0-1
             if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 3, p.state + (long)i * nb + (k1 - 1), (unsigned)k1,
                                                          p.state + (long)j * nb + (k1 - 1), (unsigned)k1, p.state + (long)i * nb + j,
                                                          (unsigned)k0, 0x40000 + t))) break;
+            if (p.prof) tm1 = wall_clock64();
             if (p.dbg != 5 && p.dbg != 6)
                 dag_upd_tile(p.M + (long)(i * CGP_NB) * p.ld + (long)j * CGP_NB, p.M + (long)(i * CGP_NB) * p.ld + (long)k0 * CGP_NB,
                              p.M + (long)(j * CGP_NB) * p.ld + (long)k0 * CGP_NB, p.ld, (k1 - k0) * CGP_NB);
             dag_publish(p.state + (long)i * nb + j, (unsigned)k1);
+            if (p.prof) { acc_wait += tm1 - tm0; acc_upd += wall_clock64() - tm1; ++acc_n; }
         }
+    }
+    if (p.prof && threadIdx.x == 0) {
+        unsigned long long* w = p.prof + (long)p.nb * 8 + (long)blockIdx.x * 4;
+        w[0] = acc_wait; w[1] = acc_trsm; w[2] = acc_upd; w[3] = acc_n;
     }
     if (p.dbg >= 5 && threadIdx.x == 0) dag_st_flag(p.ctrl + 5, 0x4000u);
 }

@@ -1,6 +1,7 @@
 // Stage-by-stage probe of k_chol_dag (csrc/dag.hpp) on a small SPD matrix: ./dag_probe <n> <dbg level> <grid>
 // Polls the stream instead of blocking, so a hung kernel ends in a message and _exit, not in a stuck process.
 #include "../cosmogp_amd/csrc/dag.hpp"
+#include "../cosmogp_amd/csrc/dag_tasks.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -11,22 +12,15 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e_), #x); return 2; } } while (0)
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 256, dbg = argc > 2 ? atoi(argv[2]) : 0, grid = argc > 3 ? atoi(argv[3]) : 2;
-    const int nb = n / 128, nr = nb + 1;
+    const int tall = argc > 4 ? atoi(argv[4]) : 1, depth = argc > 5 ? atoi(argv[5]) : 1;
+    const int nb = n / 128, nr = nb + tall;
     const long ld = n, R = (long)nr * 128;
     std::vector<double> A((size_t)R * ld, 0.);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) A[(size_t)i * ld + j] = (i == j ? 2.0 : 0.) + 0.5 * std::exp(-0.001 * (i - j) * (i - j));
     for (int j = 0; j < n; ++j) A[(size_t)(R - 1) * ld + j] = std::sin(0.1 * j);          // residual row
     std::vector<int4> t;
-    std::vector<long> applied(nb, 0);
-    for (long k = 0; k < nb; ++k) {
-        for (long i = k + 2; i < nr; ++i) t.push_back(make_int4((int)i, (int)k, 0, 0));
-        for (long j = k + 1; j < nb; ++j)
-            for (long i = j; i < nr; ++i) {
-                if (i == j && j == k + 1) continue;
-                t.push_back(make_int4((int)i, (int)j, (int)k, (int)(((k + 1) << 1) | 1)));
-            }
-    }
+    dag_build_tasks(nb, nr, depth, t);
     double *dA, *dW, *dL; int4* dT; unsigned* dS; int* dI;
     CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dW, (size_t)nb * 2048 * 8)); CK(hipMalloc(&dL, nb * 8));
     CK(hipMalloc(&dT, (t.size() + 1) * sizeof(int4))); CK(hipMalloc(&dS, (8 + nr * nb) * 4 + 64)); CK(hipMalloc(&dI, 64));
@@ -36,7 +30,9 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_chol_dag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES));
     DagParams p;
     p.M = dA; p.ld = ld; p.nb = nb; p.nr = nr; p.tasks = dT; p.ntasks = (int)t.size(); p.ctrl = dS; p.state = dS + 8;
-    p.wsW = dW; p.ldp = dL; p.info = dI; p.timeout = 30000000ll; p.dbg = dbg;
+    unsigned long long* dP; const size_t nprof = (size_t)nb * 8 + (size_t)grid * 4 + 8;
+    CK(hipMalloc(&dP, nprof * 8)); CK(hipMemset(dP, 0, nprof * 8));
+    p.wsW = dW; p.ldp = dL; p.info = dI; p.timeout = 30000000ll; p.dbg = dbg; p.prof = dP;
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     printf("launch n=%d nb=%d nr=%d tasks=%zu dbg=%d grid=%d\n", n, nb, nr, t.size(), dbg, grid); fflush(stdout);
     hipLaunchKernelGGL(k_chol_dag, dim3(grid), dim3(DAG_THREADS), DAG_LDS_BYTES, st, p);
@@ -67,6 +63,30 @@ int main(int argc, char** argv) {
     for (unsigned v : stt) printf(" %u", v);
     printf("\n");
     if (dbg == 0) {
+        std::vector<unsigned long long> pr(nprof); CK(hipMemcpy(pr.data(), dP, nprof * 8, hipMemcpyDeviceToHost));
+        // leaf lane: average time per phase (us) over the steps
+        double ph[8] = {0}; const double us = 0.01;
+        for (int k = 0; k + 1 < nb; ++k) {
+            const unsigned long long* q = &pr[(size_t)k * 8];
+            ph[0] += (q[1] - q[0]) * us;        // factor
+            ph[1] += (q[2] - q[1]) * us;        // write-back + publish
+            ph[2] += (q[3] - q[2]) * us;        // wait for the tile below
+            ph[3] += (q[4] - q[3]) * us;        // near solve + publish
+            ph[4] += (q[5] - q[4]) * us;        // wait for the next diagonal tile
+            ph[5] += (q[6] - q[5]) * us;        // load + X X^T + into LDS
+            ph[6] += (pr[(size_t)(k + 1) * 8] - q[0]) * us;   // whole step
+        }
+        const double total = (pr[(size_t)(nb - 1) * 8 + 2] - pr[0]) * us;
+        printf("leaf lane per step (us): factor %.2f  write-back %.2f  wait-below %.2f  solve %.2f  wait-diag %.2f  update %.2f  step %.2f; chain total %.1f us\n",
+               ph[0] / (nb - 1), ph[1] / (nb - 1), ph[2] / (nb - 1), ph[3] / (nb - 1), ph[4] / (nb - 1), ph[5] / (nb - 1), ph[6] / (nb - 1), total);
+        double w[4] = {0}; int nw = 0;
+        for (int g = 1; g < grid; ++g) {
+            const unsigned long long* q = &pr[(size_t)nb * 8 + (size_t)g * 4];
+            if (q[3] == 0) continue;
+            ++nw; for (int c = 0; c < 4; ++c) w[c] += q[c] * (c < 3 ? us : 1.);
+        }
+        if (nw) printf("workers (%d active): per worker wait %.1f us, TRSM %.1f us, UPD %.1f us, %.1f tasks; per task: %.2f us busy\n", nw, w[0] / nw,
+                       w[1] / nw, w[2] / nw, w[3] / nw, (w[1] + w[2]) / w[3]);
         std::vector<double> L((size_t)R * ld); CK(hipMemcpy(L.data(), dA, L.size() * 8, hipMemcpyDeviceToHost));
         // check L L^T = A on the lower triangle and the solved residual row
         double err = 0.;
