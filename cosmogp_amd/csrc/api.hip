@@ -73,6 +73,9 @@ struct Prob {
     // tri_base + c.
     long wrow0 = -1, zrow = -1, tri_base = -1;
     int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
+    bool batch_api = false;   // bound by a batched entry point: always the launch-per-step route, whatever B, so that an object's
+                              // numbers do not depend on how a caller chunks its batches (the single-launch route of cgp_fit
+                              // associates the sums differently: same result to rounding, not bit for bit)
     long w0() const { return wrow0 >= 0 ? wrow0 : Np; }
     long zr() const { return zrow >= 0 ? zrow : R - 1; }
     long rend(long Rfull, long c_end) const { return tri_base >= 0 ? std::min(Rfull, tri_base + c_end) : Rfull; }
@@ -87,7 +90,8 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
-    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 1;
+    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 36, dag_fill = 100,
+         dag_lead = 2;
     void read() {
         auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
         bulk_cap = (int)num("CGP_BULK_CAP", 0);
@@ -104,7 +108,11 @@ struct CgpEnv {
         dag_min_nb = num("CGP_DAG_MIN_NB", 2);
         dag_timeout_ms = num("CGP_DAG_TIMEOUT_MS", 4000);
         dag_grid = num("CGP_DAG_GRID", 0);
-        dag_depth = num("CGP_DAG_DEPTH", 1);
+        dag_depth = num("CGP_DAG_DEPTH", 8);
+        dag_window = num("CGP_DAG_WINDOW", 4);
+        dag_deep_min = num("CGP_DAG_DEEP_MIN", 36);
+        dag_fill = num("CGP_DAG_FILL", 100);
+        dag_lead = num("CGP_DAG_LEAD", 2);
     }
 };
 
@@ -657,27 +665,31 @@ int put_resid_row(cgp_handle* h, Prob& P) {
 // ---- single-launch factorisation (dag.hpp) --------------------------------------------------------------------
 // (task list: dag_tasks.hpp)
 bool dag_eligible(cgp_handle* h, const Prob& P) {
-    return !h->env.no_dag && P.B == 1 && P.tri_base < 0 && P.wrow0 < 0 && P.Np / NB >= h->env.dag_min_nb && P.R % NB == 0 &&
+    return !h->env.no_dag && P.B == 1 && !P.batch_api && P.tri_base < 0 && P.wrow0 < 0 && P.Np / NB >= h->env.dag_min_nb && P.R % NB == 0 &&
            P.Np <= 65536;
 }
 
 int dag_build(cgp_handle* h, long nb, long nr) {
-    const long depth = std::max<long>(1, h->env.dag_depth);
-    if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == depth) return 0;
+    if (!h->dag_cus) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->device));
+        h->dag_cus = prop.multiProcessorCount;
+    }
+    const int grid = std::max(2, h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus);
+    DagSchedule sch;
+    sch.depth = std::max<long>(1, h->env.dag_depth); sch.window = std::max<long>(1, h->env.dag_window);
+    sch.deep_min = h->env.dag_deep_min; sch.fill = 0.01 * h->env.dag_fill; sch.workers = grid - 1; sch.lead = h->env.dag_lead;
+    const long depth = sch.depth, sig = (((sch.depth * 100 + sch.window) * 1000 + sch.deep_min) * 1000 + h->env.dag_fill) * 10 + sch.lead + 7 * grid;
+    if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == sig) return 0;
     std::vector<int4> t;
-    dag_build_tasks(nb, nr, depth, t);
+    dag_build_tasks(nb, nr, sch, t);
     CHK(ensure(h, h->dtasks, t.size() * sizeof(int4)));
     HIPCHK(hipMemcpyAsync(h->dtasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t words = 8 + (size_t)nr * nb;
     CHK(ensure(h, h->dstate, (words * sizeof(unsigned) + 15) / 16 * 16));
     h->dag_ntasks = (int)t.size();
-    h->dag_nb = nb; h->dag_nr = nr; h->dag_depth_built = depth;
-    if (!h->dag_cus) {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, h->device));
-        h->dag_cus = prop.multiProcessorCount;
-    }
+    h->dag_nb = nb; h->dag_nr = nr; h->dag_depth_built = sig;
     if (h->env.debug) fprintf(stderr, "cgp: dag task list nb=%ld nr=%ld depth=%ld: %d tasks\n", nb, nr, depth, h->dag_ntasks);
     return 0;
 }
@@ -1409,6 +1421,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     Q.R = Q.Np + Mp;
     Q.sM = Q.R * Q.Np;
     Q.kps = 0;                                  // one shared parameter set (a sweep may have left 1)
+    Q.batch_api = true;
     Q.wrow0 = Q.zrow = Q.tri_base = -1;
     const long Np = Q.Np, nblk = Np / NB;
     CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
@@ -1474,6 +1487,7 @@ static int sweep_launch(cgp_handle* h, long B, const double* kp, const double* d
     Prob& Q = h->Q;
     h->have_batch = false;                     // the resident batch (if any) loses its buffers
     Q = Prob();
+    Q.batch_api = true;
     Q.B = (int)B; Q.dim = h->P.dim; Q.n = h->P.n; Q.Np = h->P.Np;
     Q.R = Q.Np + NB;
     Q.sM = Q.R * Q.Np;

@@ -263,19 +263,14 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
 // first row and column), X is stored back write-through and returned in S (K4's register layout: S[jb][0..3] =
 // columns 16 jb + 4 lu + (0..3) of row 16 wave + 4 lb + lq).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dag_trsm_rows(double* Ls, double* Ws, __amdgpu_buffer_rsrc_t rp, unsigned ldb, double (&S)[8][4]) {
+// S (already loaded: S[jb][0..3] = columns 16 jb + 4 lu + (0..3) of row 16 wave + 4 lb + lq, at byte offset aoff of rp) holds the
+// not yet solved column tiles of this wave's rows; a finished X_jb replaces S[jb] in place and is stored write-through.
+__device__ __forceinline__ void dag_trsm_rows_regs(double* Ls, double* Ws, __amdgpu_buffer_rsrc_t rp, unsigned aoff, double (&S)[8][4]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
     // wave-private 16 x 16 tile in the part of Ls that holds no strictly-lower tile (see k_trsm_panel)
     const int xg = wave < 6 ? 0 : 1, xt = wave - 6 * xg;
     double* Xs = Ls + xg * 16 * CGP_LDA + 16 + 18 * xt;
-    const unsigned aoff = (unsigned)(wave * 16 + 4 * lb + lq) * ldb + (unsigned)(4 * lu) * 8u;
-    // S holds the not yet solved column tiles of this wave's rows; a finished X_jb replaces S[jb] in place
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        d2 t0 = ldc2(rp, aoff + (unsigned)(jb * 16) * 8u), t1 = ldc2(rp, aoff + (unsigned)(jb * 16 + 2) * 8u);
-        S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
-    }
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {
         wave_lds_fence();
@@ -321,6 +316,18 @@ __device__ __forceinline__ void dag_trsm_rows(double* Ls, double* Ws, __amdgpu_b
             }
         }
     }
+}
+
+__device__ __forceinline__ void dag_trsm_rows(double* Ls, double* Ws, __amdgpu_buffer_rsrc_t rp, unsigned ldb, double (&S)[8][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
+    const unsigned aoff = (unsigned)(wave * 16 + 4 * lb + lq) * ldb + (unsigned)(4 * lu) * 8u;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d2 t0 = ldc2(rp, aoff + (unsigned)(jb * 16) * 8u), t1 = ldc2(rp, aoff + (unsigned)(jb * 16 + 2) * 8u);
+        S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
+    }
+    dag_trsm_rows_regs(Ls, Ws, rp, aoff, S);
 }
 
 // worker TRSM(i, k): stage L_kk (rows 16..127 hold strictly-lower tiles) and its T^-T blocks, then solve the tile
@@ -378,54 +385,101 @@ __device__ __noinline__ int dag_potrf_call() {
 // tile and the factor travel through LDS), so the unrolled pivot chain of the factorisation and the solve / update code
 // do not compete for registers.
 //
-// dag_leaf_near(k): solve the tile below the diagonal with the factor of (k, k) still in LDS, publish it, then turn
-// LDS into the next diagonal tile: (k+1, k+1) as the workers left it (panels 0..k-1 applied) minus X X^T.
+// dag_leaf_step(k), called with the factor of (k, k) in LDS:
+//   1. write L_kk and its T^-T blocks back (write-through), and -- once the workers have brought the tile below and the
+//      next diagonal tile up to date, ONE wait for both words -- fetch the rows of the tile below (S) and this wave's share
+//      of the next diagonal tile (36 lower 16 x 16 tiles dealt round robin over the 8 waves) while those stores drain;
+//   2. publish the factor; solve X = A(k+1, k) L_kk^-T with the factor still in LDS (the K4 code);
+//   3. X into LDS (over the factor), publish X; next diagonal tile -= X X^T, the waves' tiles interleaved so that the LDS
+//      fragment reads of one hide behind the MFMAs of the others; the result replaces X in LDS.
 // Returns 0 = aborted, 1 = done and the next diagonal tile is in LDS, 2 = done, no further diagonal tile.
-__device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned* state, const unsigned* ctrl, long long timeout, int k,
-                                          unsigned long long* prof) {
+__device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, unsigned* state, const unsigned* ctrl, long long timeout,
+                                          double* wsW, double* ldp, int* info, int k, int bad, unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) double smem_[];
     struct { double* M; long ld; int nb; unsigned* state; } p = {M, ld, nb_, state};
     double* As = smem_;
     double* Ws = smem_ + CGP_NB * CGP_LDA;
+    double* Lc = Ws + 8 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
     const unsigned ldb = (unsigned)(p.ld * 8);
     const int nb = p.nb;
+    const bool below = k + 1 < nr_, diag = k + 1 < nb;
 
-    if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr, 0, nullptr, 0,
-                                                 0x10000 + k))) return 0;
-    if (prof && tid == 0) prof[0] = wall_clock64();
-    double S[8][4];
-    dag_trsm_rows(As, Ws, dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)k * CGP_NB), ldb, S);
-    dag_publish(p.state + (long)(k + 1) * nb + k, (unsigned)(k + 1));       // barrier inside: every wave is done with L_kk
-    if (prof && tid == 0) prof[1] = wall_clock64();
-    if (k + 1 >= nb) return 2;
-
-    // next diagonal tile (workers have applied panels 0..k-1): this wave's share of its 36 lower 16 x 16 tiles (dealt
-    // round robin over the 8 waves) into registers, X into LDS
-    if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
-                                                 nullptr, 0, 0x20000 + k))) return 0;
-    if (prof && tid == 0) prof[2] = wall_clock64();
-    constexpr int NT = 5;
-    double dacc[NT][4];
-    int tti[NT], ttj[NT];
+    // ---- 1. write-back of the factor
+    {
+        const __amdgpu_buffer_rsrc_t rd = dag_rsrc(p.M + (long)(k * CGP_NB) * p.ld + (long)k * CGP_NB);
+        constexpr int NCH = CGP_NB * 64 / DAG_THREADS;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        int a = 0, b = 0;
-        dag_tile_of(min(wave + 8 * n, 35), a, b);
-        tti[n] = __builtin_amdgcn_readfirstlane(a);
-        ttj[n] = __builtin_amdgcn_readfirstlane(b);
+        for (int q = 0; q < NCH; ++q) {
+            const int idx = tid + q * DAG_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            if ((c >> 4) <= (r >> 4)) stc2(rd, (unsigned)r * ldb + (unsigned)c * 8u, *(const d2*)(As + r * CGP_LDA + c));
+        }
+        const __amdgpu_buffer_rsrc_t rw = dag_rsrc(wsW + (long)k * (8 * 256));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) stc2(rw, (unsigned)(tid + q * DAG_THREADS) * 16u, *(const d2*)(Ws + 2 * (tid + q * DAG_THREADS)));
+        double lg = 0.;
+        if (tid < CGP_NB) lg = 2. * log(As[tid * CGP_LDA + tid]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+        double* red = Lc + 128;
+        if (lane == 0 && wave < 2) red[wave] = lg;
     }
-    const __amdgpu_buffer_rsrc_t rn = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)(k + 1) * CGP_NB);
+    // the inputs of this step from the workers: tile (k+1, k) with panels 0..k-1 applied, tile (k+1, k+1) likewise
+    if (below) {
+        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, diag ? 2 : 1, p.state + (long)(k + 1) * nb + k, (unsigned)k,
+                                                     p.state + (long)(k + 1) * nb + (diag ? k + 1 : k), (unsigned)k, nullptr, 0, 0x10000 + k)))
+            return 0;
+    }
+    if (prof && tid == 0) prof[0] = wall_clock64();
+    constexpr int NT = 5;
+    double S[8][4], dacc[NT][4];
+    int tti[NT], ttj[NT];
+    const unsigned aoff = (unsigned)(wave * 16 + 4 * lb + lq) * ldb + (unsigned)(4 * lu) * 8u;
+    const __amdgpu_buffer_rsrc_t rp = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)k * CGP_NB);
+    if (below) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        if (wave + 8 * n < 36) {
-#pragma unroll
-            for (int J = 0; J < 4; ++J)
-                dacc[n][J] = ldc1(rn, (unsigned)(tti[n] * 16 + 4 * lb + lq) * ldb + (unsigned)(ttj[n] * 16 + lu + 4 * J) * 8u);
+        for (int jb = 0; jb < 8; ++jb) {
+            d2 t0 = ldc2(rp, aoff + (unsigned)(jb * 16) * 8u), t1 = ldc2(rp, aoff + (unsigned)(jb * 16 + 2) * 8u);
+            S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
         }
     }
-    // X rows of this wave (row 16 wave + 4 lb + lq, columns 16 jb + 4 lu + 0..3) -> As
+    if (diag) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int a = 0, b = 0;
+            dag_tile_of(min(wave + 8 * n, 35), a, b);
+            tti[n] = __builtin_amdgcn_readfirstlane(a);
+            ttj[n] = __builtin_amdgcn_readfirstlane(b);
+        }
+        const __amdgpu_buffer_rsrc_t rn = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)(k + 1) * CGP_NB);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (wave + 8 * n < 36) {
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+                    dacc[n][J] = ldc1(rn, (unsigned)(tti[n] * 16 + 4 * lb + lq) * ldb + (unsigned)(ttj[n] * 16 + lu + 4 * J) * 8u);
+            }
+        }
+    }
+    // ---- 2. publish the factor (the stores above have drained once the loads behind them have returned), solve
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const double* red = Lc + 128;
+        ldp[k] = red[0] + red[1];
+        if (bad != 0 && info[0] == 0) info[0] = k * CGP_NB + bad;
+        dag_st_flag(p.state + (long)k * nb + k, (unsigned)(k + 1));
+    }
+    if (prof && tid == 0) prof[1] = wall_clock64();
+    if (!below) return 2;
+    dag_trsm_rows_regs(As, Ws, rp, aoff, S);
+    // ---- 3. X over the factor in LDS, publish X
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                     // every wave is done with L_kk, every X store has drained
+    if (tid == 0) dag_st_flag(p.state + (long)(k + 1) * nb + k, (unsigned)(k + 1));
+    if (prof && tid == 0) prof[2] = wall_clock64();
+    if (!diag) return 2;
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {
         double* dst = As + (wave * 16 + 4 * lb + lq) * CGP_LDA + jb * 16 + 4 * lu;
@@ -433,15 +487,30 @@ __device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned*
         *(d2*)(dst + 2) = (d2){S[jb][2], S[jb][3]};
     }
     __syncthreads();
-    // tile (k+1, k+1) -= X X^T
+    // tile (k+1, k+1) -= X X^T : k outer, this wave's tiles inner
+#pragma unroll 1
+    for (int kc = 0; kc < 16; ++kc) {
+        d2 fa[NT], fb[NT][4];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        if (wave + 8 * n < 36) {
-            const int ti = tti[n], tj = ttj[n];
-#pragma unroll 2
-            for (int kc = 0; kc < 8; ++kc)
-                tile_mma_nt<true>(dacc[n], As + (ti * 16) * CGP_LDA + 16 * kc, As + (tj * 16) * CGP_LDA + 16 * kc, lr, lu, lq);
+        for (int n = 0; n < NT; ++n) {
+            const double* Arow = As + (tti[n] * 16) * CGP_LDA + 8 * kc;
+            const double* Brow = As + (ttj[n] * 16) * CGP_LDA + 8 * kc;
+            fa[n] = -*(const d2*)(Arow + lr * CGP_LDA + 2 * lq);
+#pragma unroll
+            for (int J = 0; J < 4; ++J) fb[n][J] = *(const d2*)(Brow + (4 * J + lu) * CGP_LDA + 2 * lq);
         }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            if (n < 4 || wave < 4) {             // waves 4..7 own four tiles (wave-uniform)
+#pragma unroll
+                for (int J = 0; J < 4; ++J) dacc[n][J] = mfma4(fa[n].x, fb[n][J].x, dacc[n][J]);
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            if (n < 4 || wave < 4) {
+#pragma unroll
+                for (int J = 0; J < 4; ++J) dacc[n][J] = mfma4(fa[n].y, fb[n][J].y, dacc[n][J]);
+            }
     }
     __syncthreads();                 // every wave has read X
 #pragma unroll
@@ -455,41 +524,6 @@ __device__ __noinline__ int dag_leaf_near(double* M, long ld, int nb_, unsigned*
     __syncthreads();
     if (prof && tid == 0) prof[3] = wall_clock64();
     return 1;
-}
-
-// write L_kk (in LDS) and its T^-T blocks back write-through, logdet part, info, then publish the factor
-__device__ __noinline__ void dag_leaf_writeback(double* M, long ld, int nb_, unsigned* state, double* wsW, double* ldp, int* info,
-                                                 int k, int bad) {
-    extern __shared__ __attribute__((aligned(16))) double smem_[];
-    struct { double* M; long ld; int nb; unsigned* state; double* wsW; double* ldp; int* info; } p = {M, ld, nb_, state, wsW, ldp, info};
-    double* As = smem_;
-    double* Ws = smem_ + CGP_NB * CGP_LDA;
-    double* Lc = Ws + 8 * 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned ldb = (unsigned)(p.ld * 8);
-    const __amdgpu_buffer_rsrc_t rd = dag_rsrc(p.M + (long)(k * CGP_NB) * p.ld + (long)k * CGP_NB);
-    constexpr int NCH = CGP_NB * 64 / DAG_THREADS;
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const int idx = tid + q * DAG_THREADS, r = idx >> 6, c = (idx & 63) * 2;
-        if ((c >> 4) <= (r >> 4)) stc2(rd, (unsigned)r * ldb + (unsigned)c * 8u, *(const d2*)(As + r * CGP_LDA + c));
-    }
-    const __amdgpu_buffer_rsrc_t rw = dag_rsrc(p.wsW + (long)k * (8 * 256));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) stc2(rw, (unsigned)(tid + q * DAG_THREADS) * 16u, *(const d2*)(Ws + 2 * (tid + q * DAG_THREADS)));
-    double lg = 0.;
-    if (tid < CGP_NB) lg = 2. * log(As[tid * CGP_LDA + tid]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
-    double* red = Lc + 128;
-    if (lane == 0 && wave < 2) red[wave] = lg;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        p.ldp[k] = red[0] + red[1];
-        if (bad != 0 && p.info[0] == 0) p.info[0] = k * CGP_NB + bad;
-        dag_st_flag(p.state + (long)k * p.nb + k, (unsigned)(k + 1));
-    }
 }
 
 __device__ void dag_leaf(const DagParams& p, double* smem) {
@@ -521,12 +555,8 @@ __device__ void dag_leaf(const DagParams& p, double* smem) {
         if (p.prof && tid == 0) p.prof[k * 8 + 1] = wall_clock64();
         dag_stamp(p.ctrl, 4u * k + 2u);
         if (p.dbg == 2) return;
-        dag_leaf_writeback(p.M, p.ld, p.nb, p.state, p.wsW, p.ldp, p.info, k, bad);
-        if (p.prof && tid == 0) p.prof[k * 8 + 2] = wall_clock64();
-        dag_stamp(p.ctrl, 4u * k + 3u);
-        if (p.dbg == 3) return;
-        if (k + 1 >= p.nr) break;
-        if (dag_leaf_near(p.M, p.ld, p.nb, p.state, p.ctrl, p.timeout, k, p.prof ? p.prof + k * 8 + 3 : nullptr) != 1) break;
+        if (dag_leaf_step(p.M, p.ld, p.nb, p.nr, p.state, p.ctrl, p.timeout, p.wsW, p.ldp, p.info, k, bad,
+                          p.prof ? p.prof + k * 8 + 2 : nullptr) != 1) break;
     }
     dag_stamp(p.ctrl, 0xffffu);
 }
@@ -538,12 +568,12 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int* cw = (int*)(smem + DAG_LDS_DOUBLES);       // [0] wait result, [1..5] ticket + descriptor
     if (blockIdx.x == 0) {
-        dag_leaf(p, smem);
+        if (p.dbg != 9) dag_leaf(p, smem);          // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
         return;
     }
     const int nb = p.nb;
     if (p.dbg != 0 && p.dbg < 5) return;
-    long long acc_wait = 0, acc_trsm = 0, acc_upd = 0, acc_n = 0, tm0 = 0, tm1 = 0;
+    long long acc_wait = 0, acc_trsm = 0, acc_upd = 0, acc_n = 0, tm0 = 0, tm1 = 0, acc_wt = 0, acc_w1 = 0;
     for (;;) {
         if (p.prof) tm0 = wall_clock64();
         const int t = __builtin_amdgcn_readfirstlane(dag_fetch(p.ctrl, p.tasks, p.ntasks));
@@ -558,7 +588,7 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
             if (p.prof) tm1 = wall_clock64();
             if (p.dbg != 5 && p.dbg != 7) dag_trsm_task(p.M, p.ld, p.wsW, i, j);
             dag_publish(p.state + (long)i * nb + j, (unsigned)(j + 1));
-            if (p.prof) { acc_wait += tm1 - tm0; acc_trsm += wall_clock64() - tm1; ++acc_n; }
+            if (p.prof) { acc_wait += tm1 - tm0; acc_wt += tm1 - tm0; acc_trsm += wall_clock64() - tm1; ++acc_n; }
         } else {
             // UPD(i, j, k0, k1): panels k0..k1-1 of rows i and j final, tile (i, j) updated through k0-1
             if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 3, p.state + (long)i * nb + (k1 - 1), (unsigned)k1,
@@ -569,12 +599,12 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
                 dag_upd_tile(p.M + (long)(i * CGP_NB) * p.ld + (long)j * CGP_NB, p.M + (long)(i * CGP_NB) * p.ld + (long)k0 * CGP_NB,
                              p.M + (long)(j * CGP_NB) * p.ld + (long)k0 * CGP_NB, p.ld, (k1 - k0) * CGP_NB);
             dag_publish(p.state + (long)i * nb + j, (unsigned)k1);
-            if (p.prof) { acc_wait += tm1 - tm0; acc_upd += wall_clock64() - tm1; ++acc_n; }
+            if (p.prof) { acc_wait += tm1 - tm0; if (k1 - k0 == 1) acc_w1 += tm1 - tm0; acc_upd += wall_clock64() - tm1; ++acc_n; }
         }
     }
     if (p.prof && threadIdx.x == 0) {
         unsigned long long* w = p.prof + (long)p.nb * 8 + (long)blockIdx.x * 4;
-        w[0] = acc_wait; w[1] = acc_trsm; w[2] = acc_upd; w[3] = acc_n;
+        w[0] = acc_wait; w[1] = acc_trsm; w[2] = acc_upd; w[3] = acc_n | ((unsigned long long)(acc_wt / 16) << 20) | ((unsigned long long)(acc_w1 / 16) << 42);
     }
     if (p.dbg >= 5 && threadIdx.x == 0) dag_st_flag(p.ctrl + 5, 0x4000u);
 }

@@ -1,0 +1,56 @@
+// host check of the task list: every dependency points backwards; every tile gets every panel exactly once
+#include "../../cosmogp_amd/csrc/dag_tasks.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+    int bad = 0;
+    for (long nb : {2, 3, 8, 17, 32, 64, 128})
+        for (long tall : {0, 1, 20})
+            for (long depth : {1, 2, 4, 8, 16})
+                for (long window : {1, 2, 4, 8})
+                    for (long dm : {0, 12, 36})
+                        for (double fill : {0.3, 1.0, 2.0}) {
+                            DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4;
+                            const long nr = nb + tall;
+                            std::vector<int4> t;
+                            dag_build_tasks(nb, nr, sc, t);
+                            std::vector<int> state(nr * nb, 0);       // simulated in list order with the leaf lane as far ahead as it can be
+                            int leaf_k = 0;                            // leaf has finished potrf(leaf_k - 1) and near trsm
+                            auto leaf_advance = [&]() {
+                                for (;;) {
+                                    int k = leaf_k;
+                                    if (k >= nb) return;
+                                    // potrf(k) needs state[k][k] >= k-1 (k>=1) and its own previous near step
+                                    if (state[k * nb + k] < (k > 0 ? k - 1 : 0)) return;
+                                    if (state[k * nb + k] != k + 1) {
+                                        if (k > 0 && state[k * nb + (k - 1)] != k) return;     // X = L(k,k-1) from the leaf itself
+                                        state[k * nb + k] = k + 1;
+                                    }
+                                    if (k + 1 < nr) {
+                                        if (state[(k + 1) * nb + k] < k) return;
+                                        if (k + 1 < nb && state[(k + 1) * nb + k + 1] < k) return;
+                                        state[(k + 1) * nb + k] = k + 1;
+                                    }
+                                    ++leaf_k;
+                                }
+                            };
+                            bool ok = true;
+                            for (size_t q = 0; q < t.size() && ok; ++q) {
+                                leaf_advance();
+                                const int i = t[q].x, j = t[q].y, k0 = t[q].z, type = t[q].w & 1, k1 = t[q].w >> 1;
+                                if (type == 0) {
+                                    if (state[j * nb + j] < j + 1 || state[i * nb + j] != j) ok = false;
+                                    state[i * nb + j] = j + 1;
+                                } else {
+                                    if (state[i * nb + k1 - 1] < k1 || state[j * nb + k1 - 1] < k1 || state[i * nb + j] != k0) ok = false;
+                                    state[i * nb + j] = k1;
+                                }
+                                if (!ok) printf("FORWARD DEP nb=%ld tall=%ld d=%ld w=%ld dm=%ld fill=%.1f at task %zu (%d,%d,%d,%d type %d)\n", nb, tall, depth, window, dm, fill, q, i, j, k0, k1, type);
+                            }
+                            leaf_advance();
+                            if (ok) for (long i = 0; i < nr; ++i) for (long j = 0; j < nb && j <= i; ++j) if (state[i * nb + j] != j + 1) { ok = false; printf("INCOMPLETE nb=%ld tall=%ld d=%ld w=%ld dm=%ld tile (%ld,%ld) state %d\n", nb, tall, depth, window, dm, i, j, state[i * nb + j]); break; }
+                            bad += !ok;
+                        }
+    printf("%d bad configurations\n", bad);
+    return bad != 0;
+}

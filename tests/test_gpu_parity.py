@@ -503,6 +503,7 @@ def test_eager_graph_lookahead_bit_identical(cg, monkeypatch):
     y = np.sin(0.05 * x) + 0.1 * rng.standard_normal(n)
     kp, dg = K.kernel_params_1d([1., 2.]), K.diag_term(n, np.full(n, 0.1), 0., 0.)
     outs = []
+    monkeypatch.setenv('CGP_NO_DAG', '1')       # the launch-per-step route (the single-launch route: tests/test_dag.py)
     for env in ({}, {'CGP_LOOKAHEAD': '1'}, {'CGP_NO_GRAPH': '1'}):
         for k in ('CGP_LOOKAHEAD', 'CGP_NO_GRAPH'):
             monkeypatch.delenv(k, raising=False)
@@ -627,7 +628,9 @@ def test_sweep_lockstep(cg):
     for row in table:
         gp.compute_log_likelihood(row, svd_method=False)
         alone.append(gp.log_likelihood[0])
-    assert np.array_equal(a, np.array(alone))
+    # (a candidate alone goes through the single-launch factorisation, a lock-step sequence through the launch-per-step
+    # route: the same tiles with the sums associated differently, equal to rounding)
+    np.testing.assert_allclose(a, np.array(alone), rtol=1e-12)
     for k in (0, 4, 8):
         ref = orc.log_likelihood_gp(y, X, 'RBF2D', table[k], 0., y_err=e, svd_method=False)[0]
         assert abs(a[k] - ref) <= 1e-11 * abs(ref)
@@ -744,10 +747,12 @@ def test_nobject_mixed_sizes_are_bucketed(cg):
         g1 = cg.gaussian_process(ys[i], xs[i], kernel='RBF1D', y_err=es[i])
         g1.hyperparameters = hyp
         g1.get_prediction(new_binning=grid, svd_method=False)
-        assert np.array_equal(g1.Prediction[0], gp.Prediction[i]) and np.array_equal(g1.variance[0], gp.variance[i])
+        # (bit for bit for objects of one 128-block; larger single objects take the single-launch route: equal to rounding)
+        np.testing.assert_allclose(g1.Prediction[0], gp.Prediction[i], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(g1.variance[0], gp.variance[i], rtol=0, atol=1e-11)
         g1.compute_log_likelihood(hyp, svd_method=False)
         total = total + g1.log_likelihood
-    assert np.array_equal(total, gp.log_likelihood)
+    np.testing.assert_allclose(total, gp.log_likelihood, rtol=1e-12)
     gp.get_prediction(new_binning=None, svd_method=False)            # own grids, bucketed too
     want = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=None, svd_method=False)
     for i in range(6):
