@@ -425,10 +425,12 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
         double* red = Lc + 128;
         if (lane == 0 && wave < 2) red[wave] = lg;
     }
-    // the inputs of this step from the workers: tile (k+1, k) with panels 0..k-1 applied, tile (k+1, k+1) likewise
+    // The tile below with panels 0..k-1 applied.  ORDER MATTERS for the no-deadlock argument of the ticket list: the factor is
+    // published after THIS wait only (its update precedes every task that needs the factor in the list); the next diagonal
+    // tile is waited for after the factor is out, because its last update is listed behind the solves of panel k.
     if (below) {
-        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, diag ? 2 : 1, p.state + (long)(k + 1) * nb + k, (unsigned)k,
-                                                     p.state + (long)(k + 1) * nb + (diag ? k + 1 : k), (unsigned)k, nullptr, 0, 0x10000 + k)))
+        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr, 0, nullptr, 0,
+                                                     0x10000 + k)))
             return 0;
     }
     if (prof && tid == 0) prof[0] = wall_clock64();
@@ -444,7 +446,22 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
             S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
         }
     }
+    // ---- 2. publish the factor (the stores above have drained once the loads behind them have returned)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const double* red = Lc + 128;
+        ldp[k] = red[0] + red[1];
+        if (bad != 0 && info[0] == 0) info[0] = k * CGP_NB + bad;
+        dag_st_flag(p.state + (long)k * nb + k, (unsigned)(k + 1));
+    }
+    if (prof && tid == 0) prof[1] = wall_clock64();
+    if (!below) return 2;
+    // this wave's share of the next diagonal tile (workers have applied panels 0..k-1): the loads land during the solve
     if (diag) {
+        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
+                                                     nullptr, 0, 0x20000 + k)))
+            return 0;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             int a = 0, b = 0;
@@ -462,17 +479,6 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
             }
         }
     }
-    // ---- 2. publish the factor (the stores above have drained once the loads behind them have returned), solve
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const double* red = Lc + 128;
-        ldp[k] = red[0] + red[1];
-        if (bad != 0 && info[0] == 0) info[0] = k * CGP_NB + bad;
-        dag_st_flag(p.state + (long)k * nb + k, (unsigned)(k + 1));
-    }
-    if (prof && tid == 0) prof[1] = wall_clock64();
-    if (!below) return 2;
     dag_trsm_rows_regs(As, Ws, rp, aoff, S);
     // ---- 3. X over the factor in LDS, publish X
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -16,22 +16,30 @@ int main(int argc, char** argv) {
                             dag_build_tasks(nb, nr, sc, t);
                             std::vector<int> state(nr * nb, 0);       // simulated in list order with the leaf lane as far ahead as it can be
                             int leaf_k = 0;                            // leaf has finished potrf(leaf_k - 1) and near trsm
+                            // the leaf lane exactly as dag_leaf_step orders its waits and publishes (sub = how far step leaf_k got)
+                            int sub = 0;
                             auto leaf_advance = [&]() {
                                 for (;;) {
-                                    int k = leaf_k;
+                                    const int k = leaf_k;
                                     if (k >= nb) return;
-                                    // potrf(k) needs state[k][k] >= k-1 (k>=1) and its own previous near step
-                                    if (state[k * nb + k] < (k > 0 ? k - 1 : 0)) return;
-                                    if (state[k * nb + k] != k + 1) {
-                                        if (k > 0 && state[k * nb + (k - 1)] != k) return;     // X = L(k,k-1) from the leaf itself
+                                    if (sub == 0) {            // factor (k, k): workers' updates through panel k-2, X from the leaf itself
+                                        if (state[k * nb + k] < (k > 0 ? k - 1 : 0)) return;
+                                        if (k > 0 && state[k * nb + (k - 1)] != k) return;
+                                        sub = 1;
+                                    }
+                                    if (sub == 1) {            // wait for the tile below, THEN publish the factor
+                                        if (k + 1 < nr && state[(k + 1) * nb + k] < k) return;
                                         state[k * nb + k] = k + 1;
+                                        sub = 2;
                                     }
-                                    if (k + 1 < nr) {
-                                        if (state[(k + 1) * nb + k] < k) return;
-                                        if (k + 1 < nb && state[(k + 1) * nb + k + 1] < k) return;
-                                        state[(k + 1) * nb + k] = k + 1;
+                                    if (sub == 2) {            // wait for the next diagonal tile, then solve and publish X
+                                        if (k + 1 < nr) {
+                                            if (k + 1 < nb && state[(k + 1) * nb + k + 1] < k) return;
+                                            state[(k + 1) * nb + k] = k + 1;
+                                        }
+                                        sub = 0;
+                                        ++leaf_k;
                                     }
-                                    ++leaf_k;
                                 }
                             };
                             bool ok = true;
