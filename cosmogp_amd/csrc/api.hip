@@ -90,8 +90,8 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
-    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 36, dag_fill = 100,
-         dag_lead = 2;
+    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 0, dag_fill = 70,
+         dag_lead = 2, dag_dmax = 8, dag_slope = 1;
     void read() {
         auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
         bulk_cap = (int)num("CGP_BULK_CAP", 0);
@@ -110,8 +110,10 @@ struct CgpEnv {
         dag_grid = num("CGP_DAG_GRID", 0);
         dag_depth = num("CGP_DAG_DEPTH", 8);
         dag_window = num("CGP_DAG_WINDOW", 4);
-        dag_deep_min = num("CGP_DAG_DEEP_MIN", 36);
-        dag_fill = num("CGP_DAG_FILL", 100);
+        dag_deep_min = 0;
+        dag_dmax = num("CGP_DAG_DMAX", 8);
+        dag_slope = num("CGP_DAG_SLOPE", 1);
+        dag_fill = num("CGP_DAG_FILL", 70);
         dag_lead = num("CGP_DAG_LEAD", 2);
     }
 };
@@ -679,7 +681,8 @@ int dag_build(cgp_handle* h, long nb, long nr) {
     DagSchedule sch;
     sch.depth = std::max<long>(1, h->env.dag_depth); sch.window = std::max<long>(1, h->env.dag_window);
     sch.deep_min = h->env.dag_deep_min; sch.fill = 0.01 * h->env.dag_fill; sch.workers = grid - 1; sch.lead = h->env.dag_lead;
-    const long depth = sch.depth, sig = (((sch.depth * 100 + sch.window) * 1000 + sch.deep_min) * 1000 + h->env.dag_fill) * 10 + sch.lead + 7 * grid;
+    sch.dmax = h->env.dag_dmax; sch.slope = h->env.dag_slope;
+    const long depth = sch.depth, sig = ((((sch.depth * 100 + sch.window) * 100 + sch.dmax) * 100 + sch.slope) * 1000 + h->env.dag_fill) * 10 + sch.lead + 7 * grid;
     if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == sig) return 0;
     std::vector<int4> t;
     dag_build_tasks(nb, nr, sch, t);

@@ -434,9 +434,13 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
             return 0;
     }
     if (prof && tid == 0) prof[0] = wall_clock64();
-    constexpr int NT = 5;
-    double S[8][4], dacc[NT][4];
-    int tti[NT], ttj[NT];
+    // this wave's share of the next diagonal tile: its lower triangle as 20 blocks of 32 rows x 16 columns (block row R =
+    // rows 32 R .. 32 R + 31, column tiles c <= 2 R + 1), dealt round robin over the 8 waves (3 / 3 / 3 / 3 / 2 / 2 / 2 / 2:
+    // five per SIMD); two row fragments share the four column fragments of a block, which keeps the X X^T update below
+    // the LDS read rate (as 36 separate 16 x 16 tiles it was LDS-bound)
+    constexpr int NT = 3;
+    double S[8][4], dacc[NT][2][4];
+    int bR[NT], bC[NT];
     const unsigned aoff = (unsigned)(wave * 16 + 4 * lb + lq) * ldb + (unsigned)(4 * lu) * 8u;
     const __amdgpu_buffer_rsrc_t rp = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)k * CGP_NB);
     if (below) {
@@ -464,18 +468,22 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
             return 0;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            int a = 0, b = 0;
-            dag_tile_of(min(wave + 8 * n, 35), a, b);
-            tti[n] = __builtin_amdgcn_readfirstlane(a);
-            ttj[n] = __builtin_amdgcn_readfirstlane(b);
+            // block b = wave + 8 n of the list R = 3 (8 blocks), 2 (6), 1 (4), 0 (2)
+            const int b = min(wave + 8 * n, 19);
+            const int R = b < 8 ? 3 : (b < 14 ? 2 : (b < 18 ? 1 : 0));
+            const int c = b - (R == 3 ? 0 : (R == 2 ? 8 : (R == 1 ? 14 : 18)));
+            bR[n] = __builtin_amdgcn_readfirstlane(R);
+            bC[n] = __builtin_amdgcn_readfirstlane(c);
         }
         const __amdgpu_buffer_rsrc_t rn = dag_rsrc(p.M + (long)((k + 1) * CGP_NB) * p.ld + (long)(k + 1) * CGP_NB);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            if (wave + 8 * n < 36) {
+            if (wave + 8 * n < 20) {
 #pragma unroll
-                for (int J = 0; J < 4; ++J)
-                    dacc[n][J] = ldc1(rn, (unsigned)(tti[n] * 16 + 4 * lb + lq) * ldb + (unsigned)(ttj[n] * 16 + lu + 4 * J) * 8u);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int J = 0; J < 4; ++J)
+                        dacc[n][r][J] = ldc1(rn, (unsigned)(bR[n] * 32 + r * 16 + 4 * lb + lq) * ldb + (unsigned)(bC[n] * 16 + lu + 4 * J) * 8u);
             }
         }
     }
@@ -493,38 +501,45 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
         *(d2*)(dst + 2) = (d2){S[jb][2], S[jb][3]};
     }
     __syncthreads();
-    // tile (k+1, k+1) -= X X^T : k outer, this wave's tiles inner
+    // tile (k+1, k+1) -= X X^T : k outer, this wave's blocks inner
 #pragma unroll 1
     for (int kc = 0; kc < 16; ++kc) {
-        d2 fa[NT], fb[NT][4];
+        d2 fa[NT][2], fb[NT][4];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const double* Arow = As + (tti[n] * 16) * CGP_LDA + 8 * kc;
-            const double* Brow = As + (ttj[n] * 16) * CGP_LDA + 8 * kc;
-            fa[n] = -*(const d2*)(Arow + lr * CGP_LDA + 2 * lq);
+            const double* Arow = As + (bR[n] * 32) * CGP_LDA + 8 * kc;
+            const double* Brow = As + (bC[n] * 16) * CGP_LDA + 8 * kc;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) fa[n][r] = -*(const d2*)(Arow + (r * 16 + lr) * CGP_LDA + 2 * lq);
 #pragma unroll
             for (int J = 0; J < 4; ++J) fb[n][J] = *(const d2*)(Brow + (4 * J + lu) * CGP_LDA + 2 * lq);
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-            if (n < 4 || wave < 4) {             // waves 4..7 own four tiles (wave-uniform)
+            if (n < 2 || wave < 4) {             // waves 4..7 own two blocks (wave-uniform)
 #pragma unroll
-                for (int J = 0; J < 4; ++J) dacc[n][J] = mfma4(fa[n].x, fb[n][J].x, dacc[n][J]);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) dacc[n][r][J] = mfma4(fa[n][r].x, fb[n][J].x, dacc[n][r][J]);
             }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-            if (n < 4 || wave < 4) {
+            if (n < 2 || wave < 4) {
 #pragma unroll
-                for (int J = 0; J < 4; ++J) dacc[n][J] = mfma4(fa[n].y, fb[n][J].y, dacc[n][J]);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) dacc[n][r][J] = mfma4(fa[n][r].y, fb[n][J].y, dacc[n][r][J]);
             }
     }
     __syncthreads();                 // every wave has read X
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        if (wave + 8 * n < 36) {
-            const int ti = tti[n], tj = ttj[n];
+        if (wave + 8 * n < 20) {
 #pragma unroll
-            for (int J = 0; J < 4; ++J) As[(ti * 16 + 4 * lb + lq) * CGP_LDA + tj * 16 + lu + 4 * J] = dacc[n][J];
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+                    As[(bR[n] * 32 + r * 16 + 4 * lb + lq) * CGP_LDA + bC[n] * 16 + lu + 4 * J] = dacc[n][r][J];
         }
     }
     __syncthreads();

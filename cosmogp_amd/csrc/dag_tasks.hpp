@@ -9,64 +9,71 @@
 //                                        every worker waiting for the panel's solves
 //     updates of the other window columns k+2 .. k+window (kept current panel by panel: they feed the leaf lane and
 //       the next solves within a few steps)
-//     the column that enters the window `lead` steps from now is brought up to date (its catch-up on entry stays short)
-//     far columns, nearest first, as many as fit beside one step of the leaf lane: each one brought up to date with ALL
-//       the panels it is behind (one update per tile, as deep as the column is behind)
-// Far columns are updated LAZILY (left-looking): an update task costs ~10 us + ~17 us per panel of depth
-// (tools/dag_probe.hip level 9), so a tile that collects 8-16 panels per visit runs near the MFMA rate and is
-// read-modified-written that many times less often; and a column is never given two updates in flight (the second would
-// only be claimed by a worker that spins until the first has finished).  What is emitted per step is what the workers can
-// do while the leaf lane runs one step (`step_us`): the critical chain (~58 us per 128 columns, latency-bound) is not held
-// back by bulk work it does not need yet, and the bulk fills its shadow.  Only columns at least `depth` panels behind
-// are picked (half of it in a second pass when the workers would otherwise idle).
-// While the trailing matrix is small (fewer than `deep_min` columns left) every column is kept current: deep catch-up
-// updates would only add latency to a chain-bound phase.  depth = 1: every update applies one panel.
+//     far columns (right of the window), LAZILY (left-looking), see below
+// Far columns: an update task costs ~10 us + ~17 us per panel of depth (tools/dag_probe.hip level 9), so a tile that
+// collects 8+ panels per visit runs near the MFMA rate and is read-modified-written that many times less often.  But
+// the updates of ONE tile are serial, so a tile that is p panels behind needs ~17 p us of latency to catch up whatever
+// the number of idle workers: the further right a column is, the more it may lag.  Per step, for the far columns from
+// the nearest one outwards:
+//   (a) the `lead` columns next to the window are caught up (at most `dmax` panels per task), so that a column enters the
+//       window at most ~`lead` panels behind;
+//   (b) a column more than  dmax + slope * (distance beyond the lead zone)  panels behind gets one task of `dmax` panels:
+//       the lag a column can still work off, `slope` panels per step, before the window reaches it;
+//   (c) then, while the workers' time beside one step of the leaf lane (`step_us` x workers x `fill`) is not used up,
+//       tiles at least `depth` panels behind get a task (nearest column first).
+// The critical chain (~58 us per 128 columns, latency-bound: potrf + solve + update of the next diagonal tile on one CU) is
+// then not held back by bulk work nobody needs yet, and that work fills the idle time of the chain-bound last part of
+// the factorisation instead.  depth = 1: every column is kept current (one panel per update).
 // The leaf lane applies panel k to the diagonal tile (k+1, k+1) itself, so the workers stop one panel short there.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <vector>
 
 struct DagSchedule {
-    long depth = 8, window = 4, deep_min = 36, workers = 255, lead = 2;
-    double step_us = 58., task_us = 10., panel_us = 17., trsm_us = 16., fill = 1.0;
+    long depth = 8, window = 4, lead = 2, dmax = 8, slope = 1, workers = 255;
+    long deep_min = 0;      // (kept for the probe's command line; unused)
+    double step_us = 58., task_us = 10., panel_us = 17., trsm_us = 16., fill = 0.7;
 };
 
 inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector<int4>& t) {
-    const long window = sc.window < 1 ? 1 : sc.window, depth = sc.depth < 1 ? 1 : sc.depth;
+    const long window = std::max<long>(1, sc.window), depth = std::max<long>(1, sc.depth), dmax = std::max(depth, sc.dmax);
     t.clear();
-    std::vector<long> applied(nb, 0);          // panels already scheduled onto tile column j
-    double spent = 0.;                         // worker time of this step's tasks (us)
-    auto column = [&](long k, long j) {        // bring column j up to date with every finished panel (through k)
-        const long k0 = applied[j], k1 = k + 1;
-        if (k0 >= k1) return;
-        for (long i = j; i < nr; ++i) {
-            long b = k1;
-            if (i == j && j == k + 1) b = k;                 // the leaf lane's share
-            if (b > k0) {
-                t.push_back(make_int4((int)i, (int)j, (int)k0, (int)((b << 1) | 1)));
-                spent += sc.task_us + sc.panel_us * (double)(b - k0);
-            }
-        }
-        applied[j] = k1;
+    std::vector<long> applied((size_t)nr * nb, 0);         // panels already scheduled onto tile (i, j)
+    double spent = 0.;                                     // worker time of this step's tasks (us)
+    // one task for tile (i, j): panels [applied, min(k + 1, applied + cap)); returns false if there was nothing to do
+    auto tile = [&](long k, long i, long j, long cap) {
+        long& a = applied[(size_t)i * nb + j];
+        long b = std::min(k + 1, a + cap);
+        if (i == j && j == k + 1) b = std::min(b, k);       // the leaf lane's share
+        if (b <= a) return false;
+        t.push_back(make_int4((int)i, (int)j, (int)a, (int)((b << 1) | 1)));
+        spent += sc.task_us + sc.panel_us * (double)(b - a);
+        a = b;
+        return true;
     };
+    auto column = [&](long k, long j, long cap) { for (long i = j; i < nr; ++i) tile(k, i, j, cap); };
     for (long i = 2; i < nr; ++i) t.push_back(make_int4((int)i, 0, 0, 0));
     for (long k = 0; k < nb; ++k) {
         spent = 0.;
         if (k + 1 < nb) {
-            column(k, k + 1);
+            column(k, k + 1, nb);
             for (long i = k + 3; i < nr; ++i) { t.push_back(make_int4((int)i, (int)(k + 1), 0, 0)); spent += sc.trsm_us; }
         }
-        for (long j = k + 2; j < nb && j <= k + window; ++j) column(k, j);
-        if (depth == 1 || nb - k <= sc.deep_min) {
-            for (long j = k + window + 1; j < nb; ++j) column(k, j);
+        for (long j = k + 2; j < nb && j <= k + window; ++j) column(k, j, nb);
+        if (depth == 1) {
+            for (long j = k + window + 1; j < nb; ++j) column(k, j, nb);
             continue;
         }
-        if (k + window + sc.lead < nb) column(k, k + window + sc.lead);
-        const double budget = sc.fill * sc.step_us * (double)sc.workers;
-        for (long need = depth; need >= 1 && spent < budget; need = need > 1 ? (need + 1) / 2 - (need == 1) : 0) {
-            for (long j = k + window + 1; j < nb && spent < budget; ++j)
-                if (k + 1 - applied[j] >= need) column(k, j);
-            if (need == 1) break;
+        for (long j = k + window + 1; j < nb; ++j) {
+            const long beyond = j - (k + window + sc.lead);        // <= 0: lead zone
+            const long allowed = beyond <= 0 ? 0 : dmax + sc.slope * beyond;
+            for (long i = j; i < nr; ++i)
+                if (k + 1 - applied[(size_t)i * nb + j] > allowed) tile(k, i, j, dmax);
         }
+        const double budget = sc.fill * sc.step_us * (double)sc.workers;
+        for (long j = k + window + 1; j < nb && spent < budget; ++j)
+            for (long i = j; i < nr && spent < budget; ++i)
+                if (k + 1 - applied[(size_t)i * nb + j] >= depth) tile(k, i, j, dmax);
     }
 }

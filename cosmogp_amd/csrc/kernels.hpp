@@ -442,7 +442,6 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     M += (long)b * sM + (long)c0 * ld + c0;
     wsW += (long)b * sW + (long)blk * (8 * 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3;
 
     CGP_STAMP(0);
     // load the block by direct global -> LDS loads: one wave instruction = one full row (128 doubles) into

@@ -213,7 +213,8 @@ int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, 
  * averages from a second, event-instrumented pass:
  *   [0] assemble K  [1] potrf_diag  [2] trsm  [3] gemm update  [4] assemble cross
  *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit
- *   [8] the part of [3] spent in the 128x64-tile form  [9] its launches  [10] its flops  [11] unused
+ *   [8] the part of [3] spent in the 128x64-tile form  [9] its launches  [10] its flops
+ *   [11] the single-launch factorisation (csrc/dag.hpp; [1]-[3] are then 0)
  * stage_ms must hold 12 doubles. */
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
 

@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
                 for (long window : {1, 2, 4, 8})
                     for (long dm : {0, 12, 36})
                         for (double fill : {0.3, 1.0, 2.0}) {
-                            DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4;
+                            DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4; sc.dmax = depth + (window % 3) * 4; sc.slope = 1 + dm / 20;
                             const long nr = nb + tall;
                             std::vector<int4> t;
                             dag_build_tasks(nb, nr, sc, t);

@@ -14,9 +14,10 @@ int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 256, dbg = argc > 2 ? atoi(argv[2]) : 0, grid = argc > 3 ? atoi(argv[3]) : 2;
     const int tall = argc > 4 ? atoi(argv[4]) : 1, depth = argc > 5 ? atoi(argv[5]) : 1, window = argc > 6 ? atoi(argv[6]) : depth;
     DagSchedule sch; sch.depth = depth; sch.window = window; sch.workers = grid - 1;
-    if (argc > 7) sch.deep_min = atoi(argv[7]);
+    if (argc > 7) sch.dmax = atoi(argv[7]);
     if (argc > 8) sch.fill = 0.01 * atoi(argv[8]);
     if (argc > 9) sch.lead = atoi(argv[9]);
+    if (argc > 10) sch.slope = atoi(argv[10]);
     const int nb = n / 128, nr = nb + tall;
     const long ld = n, R = (long)nr * 128;
     std::vector<double> A((size_t)R * ld, 0.);
