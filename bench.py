@@ -550,8 +550,9 @@ def main():
         # host (PCIe-inclusive; it is never `value`)
         adev = dev
         if batched:
+            adev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
             t_a = time.perf_counter()
-            reps_a = 3
+            reps_a = 5
             for _ in range(reps_a):
                 adev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
             dt_a = (time.perf_counter() - t_a) / reps_a
@@ -571,6 +572,8 @@ def main():
             extra['api_single_fits_per_sec'] = round(1. / dt_1, 2)
             if lock > 1:
                 bd = all_devs[0]
+                bd.batch_fit(wl['dim'], [o['x'] for o in objs], [o['y'] for o in objs], bdiags, wl['kp'], wl['xnew'], None, 0.)
+                reps_a = 5
                 t_a = time.perf_counter()
                 for _ in range(reps_a):
                     bd.batch_fit(wl['dim'], [o['x'] for o in objs], [o['y'] for o in objs], bdiags, wl['kp'], wl['xnew'],
