@@ -1834,10 +1834,10 @@ int cgp_microbench(cgp_handle* h, double* mfma_f64_tflops, double* hbm_write_gbs
     }
     if (hbm_write_gbs) {
         const long n2 = (1l << 30) / 16;
-        hipLaunchKernelGGL(k_stream_store, dim3(2048), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
+        hipLaunchKernelGGL(k_stream_store, dim3(8192), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
         HIPCHK(hipEventRecord(e0, h->stream));
         for (int i = 0; i < 5; ++i)
-            hipLaunchKernelGGL(k_stream_store, dim3(2048), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
+            hipLaunchKernelGGL(k_stream_store, dim3(8192), dim3(256), 0, h->stream, (double*)h->bout.p, n2);
         HIPCHK(hipEventRecord(e1, h->stream));
         HIPCHK(hipEventSynchronize(e1));
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));

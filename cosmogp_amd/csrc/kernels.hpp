@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "rbfmath.hpp"
 
 #define CGP_NB 128          // leaf block of the Cholesky (diagonal block lives in LDS)
 #define CGP_SB 16           // sub-block inside the leaf (pivot block of K3, column tile of K4)
@@ -64,24 +65,48 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // ------------------------------------------------------------------------------------
 // K1 / K2: covariance assembly.  Arithmetic follows the reference operation by operation
 // (cosmogp/kernel.py:71-72 for 1D; scipy 'mahalanobis' + kernel.py:140-146 for 2D) with FP
-// contraction off, so the exp() argument is bit-identical to NumPy's and only the device
-// exp differs from libm (<= 1 ulp each).
+// contraction off and every operation rounded like the reference's, so the exp() argument is
+// bit-identical to NumPy's; the division and the square root are the correctly rounded ones by the
+// short sequences of rbfmath.hpp (checked against the IEEE operations on the host,
+// tests/native/check_rbfmath.cpp), exp is rbfmath's table-based one (< 1 ulp): only it differs from
+// libm, by <= 1 ulp.  (The IEEE library forms of the three cost ~80 issue slots per element and
+// made the kernel VALU-bound at 0.36 of the HBM roof: tools/asm_ablate.hip.)
 // ------------------------------------------------------------------------------------
+__device__ const double g_exp_tab[128] = RBF_EXP_TABLE_INIT;
+
+// per-thread constants of the argument: 1D the correctly rounded reciprocal of the squared length scale
 template <int DIM>
+__device__ __forceinline__ double rbf_arg_const(const KParams& kp) {
+    return DIM == 1 ? 1.0 / kp.p0 : 0.;
+}
+
+// DIAGVI (2D): lxy = 0, the off-diagonal entries of VI are zero and their products exact zeros: 4 operations less, same bits
+template <int DIM, bool DIAGVI = false>
 __device__ __forceinline__ double rbf_exp_arg(double ux, double uy, double vx, double vy,
-                                              const KParams& kp) {
+                                              const KParams& kp, double yinv) {
 #pragma clang fp contract(off)
     if (DIM == 1) {
         double d = ux - vx;
-        return -0.5 * ((d * d) / kp.p0);
+        return -0.5 * rbf_div(d * d, kp.p0, yinv);
     } else {
         double d0 = ux - vx, d1 = uy - vy;
-        double t0 = d0 * kp.p0 + d1 * kp.p1;
-        double t1 = d0 * kp.p2 + d1 * kp.p3;
+        double t0, t1;
+        if (DIAGVI) {
+            t0 = d0 * kp.p0;
+            t1 = d1 * kp.p3;
+        } else {
+            t0 = d0 * kp.p0 + d1 * kp.p1;
+            t1 = d0 * kp.p2 + d1 * kp.p3;
+        }
         double s = d0 * t0 + d1 * t1;
-        double dist = sqrt(s);
+        double dist = rbf_sqrt_arg(s);
         return -0.5 * (dist * dist);
     }
+}
+
+// the 2^(j/64) table of rbf_exp into LDS (callers: before their first __syncthreads())
+__device__ __forceinline__ void rbf_stage_table(double* etab) {
+    for (int t = threadIdx.x; t < 128; t += blockDim.x) etab[t] = g_exp_tab[t];
 }
 
 // Train-train block: out[i][j] for i, j in [0, Np); 64 x 128 tile per workgroup, each lane
@@ -102,9 +127,12 @@ __global__ __launch_bounds__(256) void k_assemble_train(
     x += (long)b * sx;
     diag += (long)b * sd;
     const KParams kp = kpp[(long)b * kps];          // kps = 1: one parameter set per object (hyper-parameter sweeps)
+    const double yinv = rbf_arg_const<DIM>(kp);
     __shared__ double rx[64 * 2];
+    __shared__ __attribute__((aligned(16))) double etab[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64 * DIM) rx[tid] = x[(long)row0 * DIM + tid];
+    rbf_stage_table(etab);
     const int c = col0 + 2 * lane;
     double ux0, uy0 = 0., ux1, uy1 = 0.;
     if (DIM == 1) {
@@ -117,18 +145,23 @@ __global__ __launch_bounds__(256) void k_assemble_train(
     __syncthreads();
     if (row0 + 63 < n && col0 + 127 < n && (col0 + 127 < row0 || col0 > row0 + 63)) {
         // interior tile (no diagonal element, no padding): no selects
+        auto rows = [&](auto dg) {
+            constexpr bool DG = decltype(dg)::value;
 #pragma unroll 4
-        for (int rr = wave; rr < 64; rr += 4) {
-            const int i = row0 + rr;
-            const double vx = rx[rr * DIM], vy = (DIM == 2) ? rx[rr * DIM + 1] : 0.;
-            d2 o;
-            {
+            for (int rr = wave; rr < 64; rr += 4) {
+                const int i = row0 + rr;
+                const double vx = rx[rr * DIM], vy = (DIM == 2) ? rx[rr * DIM + 1] : 0.;
+                d2 o;
+                {
 #pragma clang fp contract(off)
-                o.x = kp.amp_train * exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp));
-                o.y = kp.amp_train * exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp));
+                    o.x = kp.amp_train * rbf_exp(rbf_exp_arg<DIM, DG>(ux0, uy0, vx, vy, kp, yinv), etab);
+                    o.y = kp.amp_train * rbf_exp(rbf_exp_arg<DIM, DG>(ux1, uy1, vx, vy, kp, yinv), etab);
+                }
+                *(d2*)(M + (long)i * ld + c) = o;
             }
-            *(d2*)(M + (long)i * ld + c) = o;
-        }
+        };
+        if (DIM == 2 && kp.p1 == 0. && kp.p2 == 0.) rows(std::true_type{});
+        else rows(std::false_type{});
         return;
     }
 #pragma unroll 4
@@ -138,8 +171,8 @@ __global__ __launch_bounds__(256) void k_assemble_train(
         d2 o;
         {
 #pragma clang fp contract(off)
-            double e0 = kp.amp_train * exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp));
-            double e1 = kp.amp_train * exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp));
+            double e0 = kp.amp_train * rbf_exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp, yinv), etab);
+            double e1 = kp.amp_train * rbf_exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp, yinv), etab);
             if (i < n) {
                 double dg = kp.amp_train + (use_nug2 ? (diag[i] + kp.nug2) : diag[i]);
                 o.x = (c < n) ? ((c == i) ? dg : e0) : 0.;
@@ -167,9 +200,12 @@ __global__ __launch_bounds__(256) void k_assemble_cross(
     x += (long)b * sx;
     xnew += (long)b * sxn;
     const KParams kp = kpp[(long)b * kps];
+    const double yinv = rbf_arg_const<DIM>(kp);
     __shared__ double rx[64 * 2];
+    __shared__ __attribute__((aligned(16))) double etab[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64 * DIM) rx[tid] = xnew[(long)row0 * DIM + tid];
+    rbf_stage_table(etab);
     const int c = col0 + 2 * lane;
     double ux0, uy0 = 0., ux1, uy1 = 0.;
     if (DIM == 1) {
@@ -188,8 +224,8 @@ __global__ __launch_bounds__(256) void k_assemble_cross(
         if (t < m) {
 #pragma clang fp contract(off)
             double vx = rx[rr * DIM], vy = (DIM == 2) ? rx[rr * DIM + 1] : 0.;
-            double e0 = kp.amp_cross * exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp));
-            double e1 = kp.amp_cross * exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp));
+            double e0 = kp.amp_cross * rbf_exp(rbf_exp_arg<DIM>(ux0, uy0, vx, vy, kp, yinv), etab);
+            double e1 = kp.amp_cross * rbf_exp(rbf_exp_arg<DIM>(ux1, uy1, vx, vy, kp, yinv), etab);
             o.x = (c < n) ? e0 : 0.;
             o.y = (c + 1 < n) ? e1 : 0.;
         }
@@ -876,9 +912,12 @@ __global__ __launch_bounds__(256) void k_grad_sums(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[5] = {0., 0., 0., 0., 0.};
     __shared__ double rx[64 * 2], ra[64], red[4][5];
+    __shared__ __attribute__((aligned(16))) double etab[128];
     const int n = ns[bz];
+    rbf_stage_table(etab);
     if (col0 <= row0 + 63 && row0 < n) {
         const KParams kp = *kpp;
+        const double yinv = rbf_arg_const<DIM>(kp);
         if (tid < 64 * DIM) rx[tid] = x[(long)row0 * DIM + tid];
         if (tid < 64) ra[tid] = alpha[row0 + tid];
         const int c = col0 + 2 * lane;
@@ -904,7 +943,7 @@ __global__ __launch_bounds__(256) void k_grad_sums(
                 const double ux = e ? ux1 : ux0, uy = e ? uy1 : uy0;
                 const double m = ai * (e ? ac.y : ac.x) - (e ? kv.y : kv.x);
                 const double w = (j == i) ? 1. : 2.;
-                const double E = exp(rbf_exp_arg<DIM>(ux, uy, vx, vy, kp));
+                const double E = rbf_exp(rbf_exp_arg<DIM>(ux, uy, vx, vy, kp, yinv), etab);
                 const double d0 = ux - vx, d1 = uy - vy, mE = w * m * E;
                 acc[0] += mE;
                 acc[1] += mE * d0 * d0;
@@ -975,10 +1014,16 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters) {
     if (s == 12345.678) out[0] = s;
 }
 
+// streaming-store ceiling: every wave writes 4 KB contiguous per step (four 16-byte stores per lane in flight).  The
+// one-store-per-lane grid-stride form reaches only 4.4 TB/s on a 1-GiB buffer (tools/asm_ablate.hip)
 __global__ __launch_bounds__(256) void k_stream_store(double* out, long n2) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
     d2 v = {1.0, 2.0};
-    for (; i < n2; i += (long)gridDim.x * blockDim.x) ((d2*)out)[i] = v;
+    for (long b = w * 256; b + 255 < n2; b += nw * 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ((d2*)out)[b + q * 64 + lane] = v;
+    }
 }
 
 // One 16 x 16 x 16 product in the register tiling every kernel uses: D[r][c] = C[r][c] + sum_k A[r][k] Bt[c][k]
