@@ -474,17 +474,25 @@ def main():
         ms_fit, st = rdev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
+        dag = st[11] > 0. and gemm_ms == 0.          # one object at a time: the single-launch factorisation (csrc/dag.hpp)
+        if dag:
+            # the dominant kernel is the one persistent launch: algorithmic flops = N^3/3 (factor) + N^2 (M + 1) (the M cross
+            # rows and the residual row ride through the same sweep), one launch per fit
+            gemm_ms, launches = st[11], 1.
+            flops = float(n) ** 3 / 3.0 + float(n) ** 2 * (wl['m'] + 1)
         ach = flops / (gemm_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
         for rnd in ('r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
-            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, args.workload))
+            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json' % (rnd, args.workload, '_single' if dag else ''))
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))['traffic_bytes_per_launch']
                 tsrc = os.path.relpath(tpath, ROOT)
                 break
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
-                    kernel='k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms', launches_per_fit=int(launches),
+                    kernel=('k_chol_dag (single persistent launch: leaf lane + ticketed TRSM / update tasks, '
+                            'v_mfma_f64_4x4x4_4b_f64)' if dag else 'k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms'),
+                    launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5),
                     objects_per_launch=lock,
                     measured='HIP events around every launch of one eager pass over the %d objects of a launch '
@@ -591,7 +599,9 @@ def main():
             # (lower triangle of K, 8 N (N + 1) / 2 B), measured with HIP events on one fit at a time
             extra['roofline_assembly'] = dict(bound='hbm', achieved=extra['assemble_K_GBs'], peak=SPEC_HBM_GBS, unit='GB/s',
                                               frac=extra['assemble_K_frac_of_hbm'], kernel='k_assemble_train',
-                                              note='also bounded by fp64 VALU issue (~60 instructions per element), DESIGN.md 4.2')
+                                              note='algorithmic bytes = the lower triangle, 8 N (N + 1) / 2; the kernel is fp64-VALU-bound '
+                                                   '(~40 operations per element in 2D, ~30 in 1D, every one rounded like the '
+                                                   'reference: tools/asm_ablate.hip, DESIGN.md 4.2), stores alone reach 6 TB/s')
         if not args.no_extras:
             mfma_tf, hbm_gbs = dev.microbench()
             extra.update(measured_mfma_f64_ceiling_tflops=round(mfma_tf, 2), measured_hbm_write_gbs=round(hbm_gbs, 1))
