@@ -4,9 +4,11 @@ FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled (MI355X_MICROA
 on gfx950 it counts 16-B-per-lane loads at half their bytes).
 Every update launch of the run is counted (setup, warm-up, timed steps, stage pass: all the same kernels on the
 same shapes), traffic is reported PER LAUNCH like the roofline's flops.
-usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv objects_per_launch out.json"""
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv objects_per_launch out.json [kernel substring]
+(kernel substring: default k_gemm_nt; k_chol_dag for the single-launch factorisation of `bench.py --batch 1 --streams 1`)"""
 import csv, json, sys, collections
 fetch_csv, write_csv, objs, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+KSUB = sys.argv[5] if len(sys.argv) > 5 else 'k_gemm_nt'
 
 def load(path, counter):
     tot = collections.defaultdict(float); calls = collections.defaultdict(int)
@@ -18,20 +20,20 @@ def load(path, counter):
 
 f, fc = load(fetch_csv, 'FETCH_SIZE')
 w, wc = load(write_csv, 'WRITE_SIZE')
-gemm = [k for k in f if 'k_gemm_nt' in k]
+gemm = [k for k in f if KSUB in k]
 launches = sum(fc[k] for k in gemm)
-wl = sum(wc[k] for k in w if 'k_gemm_nt' in k)
+wl = sum(wc[k] for k in w if KSUB in k)
 fetch_b = 2. * 1024. * sum(f[k] for k in gemm) / launches
-write_b = 1024. * sum(w[k] for k in w if 'k_gemm_nt' in k) / wl
+write_b = 1024. * sum(w[k] for k in w if KSUB in k) / wl
 asm = [k for k in f if 'k_assemble_train' in k]
 na = max(1, sum(fc[k] for k in asm))
 res = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`; all update '
                   'launches of the run averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (16-B-per-lane '
                   'loads on gfx950)',
-           kernel='k_gemm_nt (every launch of the run, both tile forms)', objects_per_launch=objs,
+           kernel=KSUB + ' (every launch of the run)', objects_per_launch=objs,
            launches_in_run=launches, fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b,
            traffic_bytes_per_launch=fetch_b + write_b,
-           fetch_bytes_per_fit=fetch_b * 63 / objs, write_bytes_per_fit=write_b * 63 / objs,
+           fetch_bytes_per_fit=fetch_b * (63 if KSUB == 'k_gemm_nt' else 1) / objs, write_bytes_per_fit=write_b * (63 if KSUB == 'k_gemm_nt' else 1) / objs,
            assemble_train_write_bytes_per_launch=1024. * sum(w[k] for k in w if 'k_assemble_train' in k) / na,
            assemble_train_fetch_bytes_per_launch=2. * 1024. * sum(f[k] for k in asm) / na,
            per_kernel_KB_total_in_run=dict(FETCH_SIZE={k: f[k] for k in f}, WRITE_SIZE={k: w[k] for k in w}),
