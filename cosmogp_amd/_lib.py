@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
     'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_sweep_loglik',
     'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_allgather', 'cgp_comm_allreduce',
-    'cgp_sweep_loglik_sharded', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
+    'cgp_sweep_loglik_sharded', 'cgp_bispev', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
 COMM_ID_BYTES = 128
@@ -83,6 +83,7 @@ def load_library():
         lib.cgp_comm_allgather.argtypes = [vp, _dp, _i64, _dp]
         lib.cgp_comm_allreduce.argtypes = [vp, _dp, _i64, ctypes.c_int]
         lib.cgp_sweep_loglik_sharded.argtypes = [vp, _i64, _dp, _dp, _i64, _dp, ctypes.POINTER(ctypes.c_int32)]
+        lib.cgp_bispev.argtypes = [vp, _dp, _i64, _dp, _i64, _dp, ctypes.c_int, ctypes.c_int, _dp, _i64, _dp]
         lib.cgp_bench_fit.argtypes = [vp, ctypes.c_int, _dp, _dp]
         lib.cgp_bench_fit_objects.argtypes = [vp, ctypes.c_int, _i64, _dp]
         lib.cgp_microbench.argtypes = [vp, _dp, _dp]
@@ -358,6 +359,21 @@ class Device(object):
                                         info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
         self._check(st, 'cgp_sweep_loglik')
         return ll, info
+
+    # ---- mean function (edge of the path) ---------------------------------------------
+    def bispev(self, tck, points):
+        """Bivariate B-spline `tck` = (tx, ty, c, kx, ky) of scipy.interpolate.bisplrep at points (m, 2): one launch
+        instead of one bisplev call per point (cosmogp/mean.py:63-65)."""
+        tx, ty, c, kx, ky = tck
+        tx, ty, c = _f64(tx), _f64(ty), _f64(c)
+        pts = _f64(points)
+        if pts.ndim != 2 or pts.shape[1] != 2:
+            raise ValueError('points must have shape (m, 2)')
+        out = np.empty(pts.shape[0])
+        st = self._lib.cgp_bispev(self._h, _ptr(tx), tx.size, _ptr(ty), ty.size, _ptr(c), int(kx), int(ky), _ptr(pts),
+                                  pts.shape[0], _ptr(out))
+        self._check(st, 'cgp_bispev')
+        return out
 
     # ---- multi-GPU (RCCL inside the library) -----------------------------------------
     def comm_init(self, rank, world, uid):

@@ -4,6 +4,7 @@
 #include "jacobi.hpp"
 #include "dag.hpp"
 #include "dag_tasks.hpp"
+#include "spline.hpp"
 #include "../../include/cosmogp_hip.h"
 
 #include <algorithm>
@@ -1739,6 +1740,29 @@ int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, 
 }  // extern "C"
 
 extern "C" {
+
+int cgp_bispev(cgp_handle* h, const double* tx, int64_t nx, const double* ty, int64_t ny, const double* c, int kx, int ky,
+               const double* pts, int64_t m, double* out) {
+    CHK(begin_call(h));
+    if (!tx || !ty || !c || !pts || !out || m <= 0 || kx < 1 || ky < 1 || kx > CGP_SPL_KMAX || ky > CGP_SPL_KMAX ||
+        nx < 2 * (kx + 1) || ny < 2 * (ky + 1))
+        return fail(h, CGP_E_ARG, "cgp_bispev: bad argument");
+    const size_t nc = (size_t)(nx - kx - 1) * (ny - ky - 1);
+    const size_t doubles = (size_t)nx + ny + nc + 3 * (size_t)m;
+    CHK(ensure(h, h->bout, doubles * sizeof(double)));
+    double* d = (double*)h->bout.p;
+    double *dtx = d, *dty = dtx + nx, *dc = dty + ny, *dp = dc + nc, *dout = dp + 2 * m;
+    HIPCHK(hipMemcpyAsync(dtx, tx, nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dty, ty, ny * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dc, c, nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dp, pts, 2 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_bispev, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const double*)dtx, (int)nx,
+                       (const double*)dty, (int)ny, (const double*)dc, kx, ky, (const double*)dp, (long)m, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CGP_OK;
+}
 
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms) {
     CHK(begin_call(h));

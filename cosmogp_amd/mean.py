@@ -1,7 +1,12 @@
-"""Prior mean (mirror of cosmogp/mean.py) -- O(N) host splines at the edge of the hot path
-(SURVEY.md 8a row a13): the result is uploaded with y as the residual r = y - y0."""
+"""Prior mean (mirror of cosmogp/mean.py) at the edge of the hot path: the result
+is uploaded with y as the residual r = y - y0.  The 1D cubic spline is O(N) SciPy on the host like the reference; the
+2D mean fits its bivariate spline on the host (bisplrep, O(knots)) and evaluates it at ALL points in one device launch
+(cgp_bispev) where the reference calls bisplev once per point (mean.py:63-65)."""
 import numpy as np
 import scipy.interpolate as inter
+
+#: which bisplrep task produced the last 2D fit: 1 = the reference's own call; 0 = the fallback below
+LAST_BISPLREP_TASK = None
 
 
 def interpolate_mean_1d(old_binning, mean_function, new_binning):
@@ -9,13 +14,28 @@ def interpolate_mean_1d(old_binning, mean_function, new_binning):
     return inter.InterpolatedUnivariateSpline(old_binning, mean_function)(new_binning)
 
 
-def interpolate_mean_2d(old_binning, mean_function, new_binning):
-    """Bivariate spline (bisplrep task=1) evaluated point by point (cosmogp/mean.py:36-67)."""
-    tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=1)
-    out = np.zeros(len(new_binning))
-    for k in range(len(new_binning)):
-        out[k] = inter.bisplev(new_binning[k, 0], new_binning[k, 1], tck)
-    return out
+def fit_mean_2d(old_binning, mean_function):
+    """The reference's fit, cosmogp/mean.py:58: bisplrep(..., task=1).  task=1 continues a previous fit; called cold, as
+    the reference does, it raises under recent SciPy (1.15 here: `Cannot produce output of size -4x-4`), so no output of
+    the reference exists for this branch and its parity is UNPINNED.  When that call raises, the same smoothing spline
+    is fitted from scratch (task=0, same defaults); LAST_BISPLREP_TASK says which one ran."""
+    global LAST_BISPLREP_TASK
+    old_binning = np.asarray(old_binning, dtype=np.float64)
+    try:
+        tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=1)
+        LAST_BISPLREP_TASK = 1
+    except (RuntimeError, ValueError, TypeError):
+        tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=0)
+        LAST_BISPLREP_TASK = 0
+    return tck
+
+
+def interpolate_mean_2d(old_binning, mean_function, new_binning, device=None):
+    """Bivariate spline of the mean function on new points (cosmogp/mean.py:36-67): host fit, device evaluation."""
+    from . import _lib
+    tck = fit_mean_2d(old_binning, mean_function)
+    dev = device if device is not None else _lib.default_device()
+    return dev.bispev(tck, np.asarray(new_binning, dtype=np.float64))
 
 
 def _is_1d(x):

@@ -205,6 +205,14 @@ int cgp_comm_allreduce(cgp_handle* h, double* buf, int64_t count, int op);
 int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, const double* diag,
                              int64_t chunk, double* loglik, int32_t* info);
 
+/* ---- mean function at the edge of the path ---------------------------------------
+ * interpolate_mean_2d, cosmogp/mean.py:36-67, evaluates a bivariate spline with one `bisplev` call per point
+ * (:63-65).  cgp_bispev evaluates the tensor-product B-spline (tx[nx], ty[ny], c[(nx-kx-1)*(ny-ky-1)], degrees kx,
+ * ky <= 5: the `tck` of scipy.interpolate.bisplrep, fitted on the host) at m points pts[m][2] in one launch, FITPACK's
+ * fpbisp / fpbspl arithmetic (arguments outside the base interval take the boundary value).  out[m]. */
+int cgp_bispev(cgp_handle* h, const double* tx, int64_t nx, const double* ty, int64_t ny, const double* c, int kx, int ky,
+               const double* pts, int64_t m, double* out);
+
 /* ---- measurement hooks (bench.py / tests only) ------------------------------------- */
 
 /* Device-resident timing of the last cgp_fit / cgp_batch_fit: runs `iters` fits (or batches) back to back with

@@ -189,3 +189,14 @@ class FakeDevice(object):
                     mu, var = np.zeros((B, len(m_))), np.zeros((B, len(m_)))
                 mu[b], var[b] = m_, v_
         return ll, info, mu, var
+
+
+def _fake_bispev(self, tck, points):
+    """oracle-side evaluation of a bivariate spline (scipy's bisplev per point, like cosmogp/mean.py:63-65)"""
+    import scipy.interpolate as inter
+    self.calls.append('bispev:%d' % len(points))
+    pts = np.asarray(points, dtype=np.float64)
+    return np.array([inter.bisplev(p[0], p[1], tck) for p in pts])
+
+
+FakeDevice.bispev = _fake_bispev

@@ -249,3 +249,47 @@ def test_rccl_world2(tmp_path):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
     assert [p.wait(timeout=240) for p in procs] == [0, 0]
+
+
+def test_bispev_matches_scipy(cg):
+    """2D mean function: the device evaluation of the fitted bivariate spline equals SciPy's
+    bisplev on the same `tck` at every point, also outside the base interval (FITPACK clamps).  PARITY UNPINNED against
+    the reference: its own fit call, bisplrep(task=1) cold (cosmogp/mean.py:58), raises under the SciPy of this image,
+    so no reference output exists; SciPy's evaluator on the same coefficients is the only checker."""
+    import scipy.interpolate as inter
+    rng = np.random.default_rng(123)
+    for kx, ky, npts in ((3, 3, 400), (1, 2, 150), (5, 4, 900)):
+        X = rng.uniform(-3., 7., (npts, 2))
+        z = np.sin(0.6 * X[:, 0]) * np.cos(0.4 * X[:, 1]) + 0.01 * rng.standard_normal(npts)
+        tck = inter.bisplrep(X[:, 0], X[:, 1], z, kx=kx, ky=ky, s=npts * 1e-4)
+        P = rng.uniform(-4., 8., (5000, 2))             # some points outside the data range
+        P[:7] = [[-3., -3.], [7., 7.], [tck[0][kx], tck[1][ky]], [tck[0][-1], tck[1][-1]], [100., -100.], [2., 2.], [7., -3.]]
+        got = cg.default_device().bispev(tck, P)
+        want = np.array([inter.bisplev(p[0], p[1], tck) for p in P])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
+
+
+def test_gp_2d_with_mean_function(cg):
+    """gaussian_process_2d with a 2D mean function: return_mean -> interpolate_mean_2d (host fit, device evaluation)
+    feeds the residual of the fit; checked against the same pipeline assembled from SciPy + the oracle."""
+    import scipy.interpolate as inter
+    from cosmogp_amd import mean as cmean
+    rng = np.random.default_rng(124)
+    gx = np.linspace(0., 10., 12)
+    G = np.array([[a, b] for a in gx for b in gx])
+    mean_y = 0.5 * np.sin(0.5 * G[:, 0]) + 0.2 * np.cos(0.3 * G[:, 1])
+    n, m = 300, 40
+    X = rng.uniform(0.5, 9.5, (n, 2))
+    Xn = rng.uniform(0.5, 9.5, (m, 2))
+    tck = cmean.fit_mean_2d(G, mean_y)
+    f = lambda P: np.array([inter.bisplev(p[0], p[1], tck) for p in P])
+    e = np.full(n, 0.05)
+    y = f(X) + 0.3 * np.sin(X[:, 0]) + e * rng.standard_normal(n)
+    gp = cg.gaussian_process_2d(y, X, y_err=e, Mean_Y=mean_y, Time_mean=G)
+    gp.hyperparameters = np.array([0.4, 1.5, 1.5, 0.])
+    gp.get_prediction(new_binning=Xn, svd_method=False)
+    # the same by hand: residual against the spline mean (+ the default offset diff = mean(y - mean)), oracle GP, mean added back
+    diff = np.mean(y - f(X))
+    y0, new_y0 = f(X) + diff, f(Xn) + diff
+    ref = orc.predict([y - y0], [X], 'RBF2D', [0.4, 1.5, 1.5, 0.], 0., [e], new_binning=Xn, svd_method=False)
+    np.testing.assert_allclose(gp.Prediction[0], ref['prediction'][0] + new_y0, rtol=0, atol=1e-9)
