@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -130,6 +131,11 @@ struct cgp_handle {
     // cgp_fit_fetch re-upload them, other entry points may have overwritten the shared slot meanwhile
     KParams fit_kp;
     bool have_fit_kp = false;
+    // pinned staging of the small host <-> device transfers of a call (see h2d / d2h below)
+    struct PinChunk { char* p; size_t cap, used; };
+    std::vector<PinChunk> pin;
+    struct PinOut { void* dst; const void* src; size_t bytes; size_t dpitch, spitch, width, rows; };
+    std::vector<PinOut> pin_out;
     // single-launch factorisation (dag.hpp): task list of the current tile shape, counters, number of CUs
     DevBuf dtasks, dstate;
     long dag_nb = -1, dag_nr = -1, dag_depth_built = -1;
@@ -204,6 +210,94 @@ namespace {
         if (s_ < 0) return s_;        \
     } while (0)
 
+// Wait for the handle's stream by POLLING it.  hipStreamSynchronize may park the calling thread on an interrupt and is then
+// woken with ~10 ms granularity (seen once several streams share the hardware queues: three short synchronisations of a
+// 1-ms batched call cost 30 ms); hipStreamQuery in a loop returns within microseconds of the last kernel.  The waits of
+// this library are short (a fit takes 1-100 ms), so a core spinning meanwhile is the right trade.
+hipError_t stream_wait(hipStream_t s) {
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (spins > 2000) std::this_thread::yield();
+    }
+}
+
+int fail(cgp_handle* h, int code, const char* msg);
+
+// ---- small transfers through pinned staging -----------------------------------------------------------------
+// hipMemcpyAsync to or from PAGEABLE host memory is synchronous inside the runtime and waits with the runtime's own
+// (interrupt, ~10 ms granularity under some queue layouts) wait: a 1-ms batched call then costs 20-30 ms.  Transfers up
+// to PIN_MAX bytes go through pinned chunks owned by the handle instead: host -> device = memcpy into a chunk + a truly
+// asynchronous copy; device -> host = asynchronous copy into a chunk, delivered to the caller's array by stream_sync
+// after the stream has been POLLED to completion.  Larger transfers (N x N matrices) keep the direct path.
+constexpr size_t PIN_MAX = 8u << 20;
+
+void* pin_alloc(cgp_handle* h, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (!h->pin.empty()) {
+        auto& c = h->pin.back();
+        if (c.cap - c.used >= bytes) { void* r = c.p + c.used; c.used += bytes; return r; }
+    }
+    size_t cap = std::max<size_t>(bytes, h->pin.empty() ? (1u << 20) : 2 * h->pin.back().cap);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    h->pin.push_back({(char*)p, cap, bytes});
+    return p;
+}
+
+int h2d(cgp_handle* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    void* st = bytes <= PIN_MAX ? pin_alloc(h, bytes) : nullptr;
+    if (st) {
+        std::memcpy(st, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    return 0;
+}
+
+int d2h(cgp_handle* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    void* st = bytes <= PIN_MAX ? pin_alloc(h, bytes) : nullptr;
+    if (st) {
+        HIPCHK(hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        h->pin_out.push_back({dst, st, bytes, 0, 0, 0, 0});
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    return 0;
+}
+
+// rows x width bytes, device pitch spitch -> host pitch dpitch
+int d2h_2d(cgp_handle* h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+    if (width == 0 || rows == 0) return 0;
+    void* st = width * rows <= PIN_MAX ? pin_alloc(h, width * rows) : nullptr;
+    if (st) {
+        HIPCHK(hipMemcpy2DAsync(st, width, src, spitch, width, rows, hipMemcpyDeviceToHost, h->stream));
+        h->pin_out.push_back({dst, st, width * rows, dpitch, width, width, rows});
+    } else {
+        HIPCHK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, h->stream));
+    }
+    return 0;
+}
+
+// poll the stream to completion, hand the staged results to the caller, recycle the chunks
+hipError_t stream_sync(cgp_handle* h) {
+    const hipError_t e = stream_wait(h->stream);
+    for (auto& o : h->pin_out) {
+        if (o.rows == 0) std::memcpy(o.dst, o.src, o.bytes);
+        else for (size_t r = 0; r < o.rows; ++r) std::memcpy((char*)o.dst + r * o.dpitch, (const char*)o.src + r * o.spitch, o.width);
+    }
+    h->pin_out.clear();
+    if (h->pin.size() > 1) {           // keep only the largest chunk (the next call of this size fits it at once)
+        for (size_t i = 0; i + 1 < h->pin.size(); ++i) (void)hipHostFree(h->pin[i].p);
+        h->pin.erase(h->pin.begin(), h->pin.end() - 1);
+    }
+    if (!h->pin.empty()) h->pin.back().used = 0;
+    return e;
+}
+
 int fail(cgp_handle* h, int code, const char* msg) {
     h->err = msg;
     return code;
@@ -226,7 +320,7 @@ int ensure_keep(cgp_handle* h, DevBuf& b, size_t bytes, size_t keep) {
     void* np = nullptr;
     HIPCHK(hipMalloc(&np, bytes));
     if (b.p && keep) HIPCHK(hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     if (b.p) HIPCHK(hipFree(b.p));
     b.p = np;
     b.cap = bytes;
@@ -556,13 +650,14 @@ int cgp_destroy(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
     (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    (void)stream_sync(h);
     DevBuf* all[] = {&h->csend, &h->crecv, &h->dtasks, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
                      &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
     for (DevBuf* b : all) free_buf(*b);
+    for (auto& c : h->pin) (void)hipHostFree(c.p);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
@@ -577,7 +672,7 @@ const char* cgp_last_error(cgp_handle* h) { return h ? h->err.c_str() : "null ha
 
 int cgp_synchronize(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -601,8 +696,8 @@ int upload_kp(cgp_handle* h, const double* kp, double kss_noise) {
     k.amp_train = kp[0]; k.amp_cross = kp[1]; k.p0 = kp[2]; k.p1 = kp[3]; k.p2 = kp[4]; k.p3 = kp[5];
     k.nug2 = kp[6];
     k.kss_noise = kss_noise;
-    HIPCHK(hipMemcpyAsync(h->bkp.p, &k, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(h2d(h, h->bkp.p, &k, sizeof(KParams)));
+    HIPCHK(stream_sync(h));
     return 0;
 }
 
@@ -617,14 +712,14 @@ void remember_fit_kp(cgp_handle* h, const double* kp, double kss_noise) {
 
 int restore_fit_kp(cgp_handle* h, double kss_noise) {
     h->fit_kp.kss_noise = kss_noise;
-    HIPCHK(hipMemcpyAsync(h->bkp.p, &h->fit_kp, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->bkp.p, &h->fit_kp, sizeof(KParams)));
     return 0;
 }
 
 int upload_padded(cgp_handle* h, DevBuf& b, const double* src, size_t count, size_t padded) {
     CHK(ensure(h, b, padded * sizeof(double)));
     HIPCHK(hipMemsetAsync(b.p, 0, padded * sizeof(double), h->stream));
-    if (src && count) HIPCHK(hipMemcpyAsync(b.p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (src && count) CHK(h2d(h, b.p, src, count * sizeof(double)));
     return 0;
 }
 
@@ -688,8 +783,8 @@ int dag_build(cgp_handle* h, long nb, long nr) {
     std::vector<int4> t;
     dag_build_tasks(nb, nr, sch, t);
     CHK(ensure(h, h->dtasks, t.size() * sizeof(int4)));
-    HIPCHK(hipMemcpyAsync(h->dtasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(h2d(h, h->dtasks.p, t.data(), t.size() * sizeof(int4)));
+    HIPCHK(stream_sync(h));
     const size_t words = 8 + (size_t)nr * nb;
     CHK(ensure(h, h->dstate, (words * sizeof(unsigned) + 15) / 16 * 16));
     h->dag_ntasks = (int)t.size();
@@ -731,7 +826,8 @@ int dag_check(cgp_handle* h) {
     if (!h->dag_ran) return 0;
     h->dag_ran = false;
     unsigned c[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(c, h->dstate.p, sizeof(c), hipMemcpyDeviceToHost));
+    CHK(d2h(h, c, h->dstate.p, sizeof(c)));
+    HIPCHK(stream_sync(h));
     if (c[1] != 0) {
         char msg[160];
         snprintf(msg, sizeof(msg), "single-launch factorisation gave up (abort %u, wait code 0x%x, ticket %u of %d, leaf stamp %u)",
@@ -888,8 +984,8 @@ int cgp_fit_set_data(cgp_handle* h, int dim, const double* x, const double* resi
     CHK(upload_padded(h, h->bdiag, nullptr, 0, (size_t)P.Np));       // resident diagonal := zeros
     CHK(ensure(h, h->bns, sizeof(int)));
     int ni = (int)n;
-    HIPCHK(hipMemcpyAsync(h->bns.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(h2d(h, h->bns.p, &ni, sizeof(int)));
+    HIPCHK(stream_sync(h));
     h->have_data = true;
     h->factored = false;
     h->have_fit_kp = false;
@@ -918,13 +1014,13 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     CHK(device_fit(h, P, m, mean_new != nullptr));
     double sc[2];
     int info = 0;
-    HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    CHK(d2h(h, sc, P.scal, 2 * sizeof(double)));
+    CHK(d2h(h, &info, P.info, sizeof(int)));
     if (m > 0) {
-        HIPCHK(hipMemcpyAsync(mu, P.mu, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h(h, mu, P.mu, m * sizeof(double)));
+        if (var) CHK(d2h(h, var, P.var, m * sizeof(double)));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     CHK(dag_check(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
@@ -960,8 +1056,8 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     CHK(put_resid_row(h, P));
     CHK(factor_range(h, P, 0, P.Np, P.Np, P.R, false));
     CHK(launch_finish(h, P, m, false, mean_new != nullptr));
-    HIPCHK(hipMemcpyAsync(mu, P.mu, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CHK(d2h(h, mu, P.mu, m * sizeof(double)));
+    if (var) CHK(d2h(h, var, P.var, m * sizeof(double)));
     if (cov) {
         // K(new,new; nugget) - W W^T, full matrix   [Gaussian_process.py:356-361]
         CHK(ensure(h, h->bC, (size_t)Mp * Mp * sizeof(double)));
@@ -969,7 +1065,7 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
         CHK(ensure(h, h->bns2, sizeof(int)));
         CHK(ensure(h, h->bout, (size_t)m * m * sizeof(double)));
         int mi = (int)m;
-        HIPCHK(hipMemcpyAsync(h->bns2.p, &mi, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        CHK(h2d(h, h->bns2.p, &mi, sizeof(int)));
         hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mp, kss_noise);
         CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, Mp, 0, P.xnew, 0, (double*)h->bdiag2.p, 0,
                                   (int*)h->bns2.p, Mp, false, false));
@@ -978,9 +1074,9 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
         hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->bC.p, Mp,
                            (double*)h->bout.p, (int)m, 0);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(cov, h->bout.p, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h(h, cov, h->bout.p, (size_t)m * m * sizeof(double)));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -1006,10 +1102,10 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     CHK(device_grad(h, P));
     double sc[2];
     int info = 0;
-    HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(sums, h->bgrad.p, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, sc, P.scal, 2 * sizeof(double)));
+    CHK(d2h(h, &info, P.info, sizeof(int)));
+    CHK(d2h(h, sums, h->bgrad.p, 5 * sizeof(double)));
+    HIPCHK(stream_sync(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
@@ -1055,10 +1151,10 @@ int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t*
     CHK(device_grad(h, Q));
     std::vector<double> sc((size_t)B * 2), gs((size_t)B * 8);
     std::vector<int> hinfo(B);
-    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(gs.data(), h->bgrad.p, gs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
+    CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
+    CHK(d2h(h, gs.data(), h->bgrad.p, gs.size() * sizeof(double)));
+    HIPCHK(stream_sync(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1101,8 +1197,8 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
                 tab[(r * npairs + k) * 2 + 1] = (int)b;
             }
         CHK(ensure(h, h->jpairs, tab.size() * sizeof(int)));
-        HIPCHK(hipMemcpyAsync(h->jpairs.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(h2d(h, h->jpairs.p, tab.data(), tab.size() * sizeof(int)));
+        HIPCHK(stream_sync(h));
         h->jnb = nb;
     }
     double* K = (double*)h->jK.p;
@@ -1144,8 +1240,8 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
         }
         HIPCHK(hipGetLastError());
         int rot = 0;
-        HIPCHK(hipMemcpyAsync(&rot, (char*)st + offsetof(JacStat, rotations), sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(d2h(h, &rot, (char*)st + offsetof(JacStat, rotations), sizeof(int)));
+        HIPCHK(stream_sync(h));
         if (h->env.debug) fprintf(stderr, "cgp: eigen sweep %d: %d pivot blocks rotated\n", sweep, rot);
         if (rot == 0) break;
     }
@@ -1183,8 +1279,8 @@ int square_to_host(cgp_handle* h, const double* src, long ld, long n, int mode, 
     CHK(ensure(h, h->bout, (size_t)n * n * sizeof(double)));
     hipLaunchKernelGGL(k_extract_square, dim3(512), dim3(256), 0, h->stream, src, ld, (double*)h->bout.p, (int)n, mode);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, h->bout.p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, out, h->bout.p, (size_t)n * n * sizeof(double)));
+    HIPCHK(stream_sync(h));
     return 0;
 }
 
@@ -1224,22 +1320,22 @@ int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
     h->factored = false;
     CHK(bind_single(h, 0, false));
     CHK(ensure(h, h->bC, (size_t)std::max<long>(n * ldk, P.Np * P.Np) * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->bC.p, K, (size_t)n * ldk * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->bC.p, K, (size_t)n * ldk * sizeof(double)));
     hipLaunchKernelGGL(k_pad_square, dim3(512), dim3(256), 0, h->stream, (const double*)h->bC.p, (long)ldk, P.M,
                        P.Np, (int)n, (int)P.Np);
     HIPCHK(hipGetLastError());
     CHK(ensure(h, h->bns, sizeof(int)));
     int ni = (int)n;
-    HIPCHK(hipMemcpyAsync(h->bns.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->bns.p, &ni, sizeof(int)));
     P.ns = (int*)h->bns.p;
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
     CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
     const long nblk = P.Np / NB;
     std::vector<double> parts(nblk);
     int info = 0;
-    HIPCHK(hipMemcpyAsync(parts.data(), P.ldp, nblk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(&info, P.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, parts.data(), P.ldp, nblk * sizeof(double)));
+    CHK(d2h(h, &info, P.info, sizeof(int)));
+    HIPCHK(stream_sync(h));
     if (info != 0) return info;
     double ld_sum = 0.;
     for (double v : parts) ld_sum += v;
@@ -1256,13 +1352,13 @@ int cgp_svd_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, doub
     const long Np = round_up(n, NB);
     CHK(ensure(h, h->bC, (size_t)std::max<long>(n * ldk, Np * Np) * sizeof(double)));
     CHK(ensure(h, h->jK, (size_t)Np * Np * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->bC.p, K, (size_t)n * ldk * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->bC.p, K, (size_t)n * ldk * sizeof(double)));
     hipLaunchKernelGGL(k_pad_square, dim3(512), dim3(256), 0, h->stream, (const double*)h->bC.p, (long)ldk,
                        (double*)h->jK.p, Np, (int)n, (int)Np);
     HIPCHK(hipGetLastError());
     CHK(device_eig_pinv(h, Np, n, thresh));
     double res[2];
-    HIPCHK(hipMemcpyAsync(res, h->jres.p, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    CHK(d2h(h, res, h->jres.p, sizeof(res)));
     CHK(square_to_host(h, (double*)h->bC.p, Np, n, 0, inv_out));
     if (logdet_out) *logdet_out = res[0];
     if (n_dropped) *n_dropped = (int64_t)res[1];
@@ -1306,11 +1402,11 @@ int cgp_fit_svd(cgp_handle* h, const double* kp, const double* diag, const doubl
                        (const int*)P.ns, P.mu, P.var, P.scal);
     HIPCHK(hipGetLastError());
     double sc[2], res[2];
-    HIPCHK(hipMemcpyAsync(sc, P.scal, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(res, h->jres.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CHK(d2h(h, sc, P.scal, 2 * sizeof(double)));
+    CHK(d2h(h, res, h->jres.p, 2 * sizeof(double)));
     if (m > 0) {
-        HIPCHK(hipMemcpyAsync(mu, P.mu, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        if (var) HIPCHK(hipMemcpyAsync(var, P.var, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h(h, mu, P.mu, m * sizeof(double)));
+        if (var) CHK(d2h(h, var, P.var, m * sizeof(double)));
     }
     if (cov && m > 0) {
         // K(new,new; nugget) - T H'  [Gaussian_process.py:356-361 with the pseudo-inverse]
@@ -1319,7 +1415,7 @@ int cgp_fit_svd(cgp_handle* h, const double* kp, const double* diag, const doubl
         CHK(ensure(h, h->bns2, sizeof(int)));
         CHK(ensure(h, h->bout, (size_t)m * m * sizeof(double)));
         int mi = (int)m;
-        HIPCHK(hipMemcpyAsync(h->bns2.p, &mi, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        CHK(h2d(h, h->bns2.p, &mi, sizeof(int)));
         hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mp, kss_noise);
         CHK(launch_assemble_train(h, P.dim, 1, (double*)h->jVD.p, Mp, 0, P.xnew, 0, (double*)h->bdiag2.p, 0,
                                   (int*)h->bns2.p, Mp, false, false));
@@ -1328,9 +1424,9 @@ int cgp_fit_svd(cgp_handle* h, const double* kp, const double* diag, const doubl
         hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->jVD.p, Mp,
                            (double*)h->bout.p, (int)m, 0);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(cov, h->bout.p, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h(h, cov, h->bout.p, (size_t)m * m * sizeof(double)));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = res[0];
     if (n_dropped) *n_dropped = (int64_t)res[1];
@@ -1348,24 +1444,22 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xn
     CHK(upload_padded(h, h->box, x, (size_t)n * dim, (size_t)Np * dim));
     CHK(ensure(h, h->bns2, sizeof(int)));
     int ni = (int)n;
-    HIPCHK(hipMemcpyAsync(h->bns2.p, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->bns2.p, &ni, sizeof(int)));
     if (!xnew) {
         CHK(upload_padded(h, h->bdiag2, diag, diag ? (size_t)n : 0, (size_t)Np));
         CHK(ensure(h, h->bC, (size_t)Np * Np * sizeof(double)));
         CHK(launch_assemble_train(h, dim, 1, (double*)h->bC.p, Np, 0, (double*)h->box.p, 0, (double*)h->bdiag2.p, 0,
                                   (int*)h->bns2.p, Np, false, true));
-        HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), n,
-                                hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h_2d(h, out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), n));
     } else {
         const long Mp = round_up(m, NB);
         CHK(upload_padded(h, h->boxn, xnew, (size_t)m * dim, (size_t)Mp * dim));
         CHK(ensure(h, h->bC, (size_t)Mp * Np * sizeof(double)));
         CHK(launch_assemble_cross(h, dim, 1, (double*)h->bC.p, Np, 0, (double*)h->box.p, 0, (double*)h->boxn.p, 0,
                                   (int*)h->bns2.p, Np, Mp, m));
-        HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), m,
-                                hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h_2d(h, out, ld * sizeof(double), h->bC.p, Np * sizeof(double), n * sizeof(double), m));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -1399,11 +1493,11 @@ int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, con
     CHK(ensure(h, h->qr, hr.size() * sizeof(double)));
     CHK(ensure(h, h->qdiag, hd.size() * sizeof(double)));
     CHK(ensure(h, h->qns, B * sizeof(int)));
-    HIPCHK(hipMemcpyAsync(h->qx.p, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qr.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qdiag.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));       // host staging vectors die here
+    CHK(h2d(h, h->qx.p, hx.data(), hx.size() * sizeof(double)));
+    CHK(h2d(h, h->qr.p, hr.data(), hr.size() * sizeof(double)));
+    CHK(h2d(h, h->qdiag.p, hd.data(), hd.size() * sizeof(double)));
+    CHK(h2d(h, h->qns.p, hn.data(), B * sizeof(int)));
+    HIPCHK(stream_sync(h));       // host staging vectors die here
     h->have_batch = true;
     return CGP_OK;
 }
@@ -1441,8 +1535,8 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
         for (long b = 0; b < B; ++b)
             std::memcpy(&hxn[(size_t)b * Mp * dim], xnew + (size_t)b * m * dim, m * dim * sizeof(double));
         CHK(ensure(h, h->qxnew, hxn.size() * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(h->qxnew.p, hxn.data(), hxn.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        CHK(h2d(h, h->qxnew.p, hxn.data(), hxn.size() * sizeof(double)));
+        HIPCHK(stream_sync(h));
     } else {
         CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)Mp * dim));
     }
@@ -1462,16 +1556,14 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     CHK(device_fit(h, Q, m, mean_new != nullptr));
     std::vector<double> sc((size_t)B * 2);
     std::vector<int> hinfo(B);
-    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
+    CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
     if (m > 0) {
-        HIPCHK(hipMemcpy2DAsync(mu, m * sizeof(double), Q.mu, Mp * sizeof(double), m * sizeof(double), B,
-                                hipMemcpyDeviceToHost, h->stream));
+        CHK(d2h_2d(h, mu, m * sizeof(double), Q.mu, Mp * sizeof(double), m * sizeof(double), B));
         if (var)
-            HIPCHK(hipMemcpy2DAsync(var, m * sizeof(double), Q.var, Mp * sizeof(double), m * sizeof(double), B,
-                                    hipMemcpyDeviceToHost, h->stream));
+            CHK(d2h_2d(h, var, m * sizeof(double), Q.var, Mp * sizeof(double), m * sizeof(double), B));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     CHK(dag_check(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
@@ -1514,9 +1606,9 @@ static int sweep_launch(cgp_handle* h, long B, const double* kp, const double* d
         ks[b].amp_train = k[0]; ks[b].amp_cross = k[1]; ks[b].p0 = k[2]; ks[b].p1 = k[3]; ks[b].p2 = k[4]; ks[b].p3 = k[5];
         ks[b].nug2 = k[6]; ks[b].kss_noise = 0.;
     }
-    HIPCHK(hipMemcpyAsync(h->bkp.p, ks.data(), B * sizeof(KParams), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->qns.p, hn.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(h2d(h, h->bkp.p, ks.data(), B * sizeof(KParams)));
+    CHK(h2d(h, h->qns.p, hn.data(), B * sizeof(int)));
+    HIPCHK(stream_sync(h));
     Q.M = (double*)h->qM.p;
     Q.x = (double*)h->bx.p; Q.sx = 0;
     Q.r = (double*)h->br.p; Q.sr = 0;
@@ -1548,9 +1640,9 @@ int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double*
     Prob& Q = h->Q;
     std::vector<double> sc((size_t)B * 2);
     std::vector<int> hinfo(B);
-    HIPCHK(hipMemcpyAsync(sc.data(), Q.scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(hinfo.data(), Q.info, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
+    CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
+    HIPCHK(stream_sync(h));
     for (long b = 0; b < B; ++b) {
         loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1646,7 +1738,7 @@ int cgp_comm_destroy(cgp_handle* h) {
     if (!h->comm) return CGP_OK;
     Rccl* R = rccl();
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    (void)stream_sync(h);
     ncclComm_t c = h->comm;
     h->comm = nullptr;
     h->comm_world = 1;
@@ -1664,10 +1756,10 @@ int cgp_comm_allgather(cgp_handle* h, const double* send, int64_t count, double*
     const size_t bytes = (size_t)count * sizeof(double);
     CHK(ensure(h, h->csend, bytes));
     CHK(ensure(h, h->crecv, bytes * h->comm_world));
-    HIPCHK(hipMemcpyAsync(h->csend.p, send, bytes, hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, h->csend.p, send, bytes));
     NCCLCHK(R->AllGather(h->csend.p, h->crecv.p, (size_t)count, ncclDouble, h->comm, h->stream));
-    HIPCHK(hipMemcpyAsync(recv, h->crecv.p, bytes * h->comm_world, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, recv, h->crecv.p, bytes * h->comm_world));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -1679,11 +1771,11 @@ int cgp_comm_allreduce(cgp_handle* h, double* buf, int64_t count, int op) {
         return fail(h, CGP_E_ARG, "cgp_comm_allreduce: bad argument");
     const size_t n = (size_t)std::max<int64_t>(count, 1);      // count = 0: one dummy element = a barrier
     CHK(ensure(h, h->csend, n * sizeof(double)));
-    if (count > 0) HIPCHK(hipMemcpyAsync(h->csend.p, buf, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (count > 0) CHK(h2d(h, h->csend.p, buf, n * sizeof(double)));
     else HIPCHK(hipMemsetAsync(h->csend.p, 0, sizeof(double), h->stream));
     NCCLCHK(R->AllReduce(h->csend.p, h->csend.p, n, ncclDouble, op == CGP_OP_MAX ? ncclMax : ncclSum, h->comm, h->stream));
-    if (count > 0) HIPCHK(hipMemcpyAsync(buf, h->csend.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (count > 0) CHK(d2h(h, buf, h->csend.p, n * sizeof(double)));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -1726,8 +1818,8 @@ int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, 
     // the one collective of the path: per-candidate results of every rank, device to device
     NCCLCHK(R->AllGather(h->csend.p, h->crecv.p, (size_t)per * 2, ncclDouble, h->comm, h->stream));
     std::vector<double> all((size_t)per * 2 * W);
-    HIPCHK(hipMemcpyAsync(all.data(), h->crecv.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, all.data(), h->crecv.p, all.size() * sizeof(double)));
+    HIPCHK(stream_sync(h));
     for (long q = 0; q < W; ++q)
         for (long u = lo_of(q); u < lo_of(q + 1); ++u) {
             const double* e = &all[(size_t)(q * per + (u - lo_of(q))) * 2];
@@ -1752,15 +1844,15 @@ int cgp_bispev(cgp_handle* h, const double* tx, int64_t nx, const double* ty, in
     CHK(ensure(h, h->bout, doubles * sizeof(double)));
     double* d = (double*)h->bout.p;
     double *dtx = d, *dty = dtx + nx, *dc = dty + ny, *dp = dc + nc, *dout = dp + 2 * m;
-    HIPCHK(hipMemcpyAsync(dtx, tx, nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dty, ty, ny * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dc, c, nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dp, pts, 2 * m * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, dtx, tx, nx * sizeof(double)));
+    CHK(h2d(h, dty, ty, ny * sizeof(double)));
+    CHK(h2d(h, dc, c, nc * sizeof(double)));
+    CHK(h2d(h, dp, pts, 2 * m * sizeof(double)));
     hipLaunchKernelGGL(k_bispev, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const double*)dtx, (int)nx,
                        (const double*)dty, (int)ny, (const double*)dc, kx, ky, (const double*)dp, (long)m, dout);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, dout, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, out, dout, m * sizeof(double)));
+    HIPCHK(stream_sync(h));
     return CGP_OK;
 }
 
@@ -1792,7 +1884,7 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
         const int reps = std::min(iters, 3);
         for (int i = 0; i < reps; ++i) CHK(device_fit(h, P, h->last_m, h->last_has_mean));
         h->profiling = false;
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(stream_sync(h));
         for (auto& r : h->recs) {
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
@@ -1889,13 +1981,13 @@ int cgp_selftest_mfma(cgp_handle* h) {
         }
     CHK(ensure(h, h->bout, 2048 * sizeof(double)));
     double* d = (double*)h->bout.p;
-    HIPCHK(hipMemcpyAsync(d, A, sizeof(A), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + 256, Bt, sizeof(Bt), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d + 512, C, sizeof(C), hipMemcpyHostToDevice, h->stream));
+    CHK(h2d(h, d, A, sizeof(A)));
+    CHK(h2d(h, d + 256, Bt, sizeof(Bt)));
+    CHK(h2d(h, d + 512, C, sizeof(C)));
     hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, h->stream, d, d + 256, d + 512, d + 768);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(D, d + 768, sizeof(D), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    CHK(d2h(h, D, d + 768, sizeof(D)));
+    HIPCHK(stream_sync(h));
     for (int i = 0; i < 256; ++i)
         if (D[i] != ref[i]) return fail(h, 1, "f64 4x4x4 MFMA A/B/D lane map mismatch");
     // E_blk[i][j] = sum_k A[4 blk + i][k] * D[4 blk + k][j]   (k, j in 0..3: D block rows are the k index)
