@@ -334,13 +334,19 @@ def main():
         comm = multigpu.Comm(dev, rank=rank, world=world)
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
+    # Batches of objects with >= 16 tile columns (N >= 2048) are factored by ONE persistent launch per group of objects
+    # (csrc/dag.hpp, several leaf lanes + one interleaved task list); smaller objects and CGP_NO_DAG_BATCH=1 take one launch
+    # per step.  The persistent launch owns every CU, so one handle is enough to fill the GPU.
+    dag_batch = (not batched and -(-wl['n'] // 128) >= int(os.environ.get('CGP_DAG_BATCH_MIN_NB', '16'))
+                 and 'CGP_NO_DAG_BATCH' not in os.environ and 'CGP_NO_DAG' not in os.environ)
     if batched:
         lock = 1
     elif 'sweep' in wl:
         lock = len(wl['sweep']) if args.batch < 0 else max(1, args.batch)      # candidates per launch sequence
     else:
-        lock = 8 if args.batch < 0 else max(1, args.batch)                     # objects per launch sequence
-    nstreams = args.streams if args.streams > 0 else (4 if batched else (2 if lock > 1 else 4))
+        # objects per launch sequence
+        lock = (16 if (dag_batch and wl['n'] <= 4096) else 8) if args.batch < 0 else max(1, args.batch)
+    nstreams = args.streams if args.streams > 0 else (4 if batched else ((1 if dag_batch else 2) if lock > 1 else 4))
     if 'sweep' in wl and args.streams <= 0:
         nstreams = 1 if lock > 1 else 4
     # Independent fits are the unit of this path (objects, candidates): with several in flight the
@@ -474,23 +480,25 @@ def main():
         ms_fit, st = rdev.bench_fit(min(args.steps, 5) if 'sweep' not in wl else 1, stages=True)
         n = wl['n']
         gemm_ms, launches, flops = st[3], st[6], st[7]
-        dag = st[11] > 0. and gemm_ms == 0.          # one object at a time: the single-launch factorisation (csrc/dag.hpp)
+        dag = st[11] > 0. and gemm_ms == 0.          # the single-launch factorisation (csrc/dag.hpp), one or several objects
+        nobj_pass = (wl['B'] if batched else lock) if (lock > 1 or batched) else 1
         if dag:
-            # the dominant kernel is the one persistent launch: algorithmic flops = N^3/3 (factor) + N^2 (M + 1) (the M cross
-            # rows and the residual row ride through the same sweep), one launch per fit
-            gemm_ms, launches = st[11], 1.
-            flops = float(n) ** 3 / 3.0 + float(n) ** 2 * (wl['m'] + 1)
+            # the dominant kernel is the persistent launch: algorithmic flops per object = N^3/3 (factor) + N^2 (M + 1) (the M
+            # cross rows and the residual row ride through the same sweep); one launch per group of objects
+            gemm_ms, launches = st[11], max(1., launches)
+            flops = nobj_pass * (float(n) ** 3 / 3.0 + float(n) ** 2 * (wl.get('m', 0) + 1))
         ach = flops / (gemm_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
         for rnd in ('r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
-            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json' % (rnd, args.workload, '_single' if dag else ''))
+            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json'
+                                 % (rnd, args.workload, ('_single' if nobj_pass == 1 else '_dagbatch') if dag else ''))
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))['traffic_bytes_per_launch']
                 tsrc = os.path.relpath(tpath, ROOT)
                 break
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
-                    kernel=('k_chol_dag (single persistent launch: leaf lane + ticketed TRSM / update tasks, '
+                    kernel=('k_chol_dag (persistent launch: one leaf lane per object + ticketed TRSM / update tasks, '
                             'v_mfma_f64_4x4x4_4b_f64)' if dag else 'k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms'),
                     launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5),
@@ -626,6 +634,9 @@ def main():
                                 fits_per_step_per_gpu=units_per_step,
                                 fits_in_flight_per_gpu=nstreams * (wl['B'] if batched else lock),
                                 objects_per_launch_sequence=(wl['B'] if batched else lock), handles_per_gpu=nstreams,
+                                factorisation_route=('single launch: persistent tile-DAG kernel k_chol_dag, one leaf lane per object'
+                                                     if (roof is not None and 'k_chol_dag' in roof['kernel'])
+                                                     else 'one launch per step: k_potrf_diag / k_trsm_panel / k_gemm_nt'),
                                 parallelism='independent fits, 1 rank per GPU, %d handles (HIP streams) per GPU, '
                                             '%d distinct objects per launch sequence' % (nstreams, wl['B'] if batched else lock)),
                     roofline=roof)

@@ -94,6 +94,11 @@ struct CgpEnv {
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
     long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 0, dag_fill = 70,
          dag_lead = 2, dag_dmax = 8, dag_slope = 1;
+    // the same for the batched entry points (several objects per launch: the workers are never short of work, so the list
+    // is lazier); at most dag_bmax objects (= leaf lanes) per launch, tile columns >= dag_batch_min_nb
+    long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 16, dag_bwindow = 2, dag_bfill = 70, dag_blead = 2, dag_bdmax = 16,
+         dag_bslope = 1, dag_border = 1;
+    bool no_dag_batch = false;
     void read() {
         auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
         bulk_cap = (int)num("CGP_BULK_CAP", 0);
@@ -117,6 +122,16 @@ struct CgpEnv {
         dag_slope = num("CGP_DAG_SLOPE", 1);
         dag_fill = num("CGP_DAG_FILL", 70);
         dag_lead = num("CGP_DAG_LEAD", 2);
+        no_dag_batch = getenv("CGP_NO_DAG_BATCH") != nullptr;
+        dag_batch_min_nb = num("CGP_DAG_BATCH_MIN_NB", 16);
+        dag_bmax = std::max(0l, std::min(64l, num("CGP_DAG_BMAX", 0)));       // 0: by the tile count (dag_groups)
+        dag_bdepth = num("CGP_DAG_BDEPTH", 16);
+        dag_bwindow = num("CGP_DAG_BWINDOW", 2);
+        dag_bfill = num("CGP_DAG_BFILL", 70);
+        dag_blead = num("CGP_DAG_BLEAD", 2);
+        dag_bdmax = num("CGP_DAG_BDMAX", 16);
+        dag_bslope = num("CGP_DAG_BSLOPE", 1);
+        dag_border = num("CGP_DAG_BORDER", 1);
     }
 };
 
@@ -136,11 +151,13 @@ struct cgp_handle {
     std::vector<PinChunk> pin;
     struct PinOut { void* dst; const void* src; size_t bytes; size_t dpitch, spitch, width, rows; };
     std::vector<PinOut> pin_out;
-    // single-launch factorisation (dag.hpp): task list of the current tile shape, counters, number of CUs
-    DevBuf dtasks, dstate;
-    long dag_nb = -1, dag_nr = -1, dag_depth_built = -1;
-    int dag_ntasks = 0, dag_cus = 0;
-    bool dag_ran = false;
+    // single-launch factorisation (dag.hpp): task lists by (tile shape, objects per launch, schedule), counters, number of CUs
+    struct DagList { DevBuf tasks; long nb = -1, nr = -1, nmat = -1, sig = -1; int ntasks = 0; unsigned long used = 0; };
+    std::vector<DagList> dag_lists;
+    unsigned long dag_clock = 0;
+    DevBuf dstate;
+    int dag_cus = 0;
+    long dag_groups_ran = 0;             // launches of the last fit whose control words dag_check has to read
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
     std::vector<hipEvent_t> fork_events;
@@ -651,7 +668,8 @@ int cgp_destroy(cgp_handle* h) {
     (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
     (void)stream_sync(h);
-    DevBuf* all[] = {&h->csend, &h->crecv, &h->dtasks, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
+    for (auto& l : h->dag_lists) free_buf(l.tasks);
+    DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
@@ -761,41 +779,104 @@ int put_resid_row(cgp_handle* h, Prob& P) {
 
 
 // ---- single-launch factorisation (dag.hpp) --------------------------------------------------------------------
-// (task list: dag_tasks.hpp)
+// (task list: dag_tasks.hpp).  cgp_fit binds ONE object: its list is tuned for the critical chain.  The batched entry
+// points (cgp_batch_fit, cgp_sweep_loglik: Prob::batch_api) factor up to dag_bmax objects per launch from the interleaved
+// list; an object's arithmetic depends on neither the batch size nor the grouping, so a caller may chunk its batches as it
+// likes and get the same bits.
+bool dag_batch_route(const Prob& P) { return P.batch_api || P.B > 1; }
+
 bool dag_eligible(cgp_handle* h, const Prob& P) {
-    return !h->env.no_dag && P.B == 1 && !P.batch_api && P.tri_base < 0 && P.wrow0 < 0 && P.Np / NB >= h->env.dag_min_nb && P.R % NB == 0 &&
-           P.Np <= 65536;
+    if (h->env.no_dag || P.tri_base >= 0 || P.wrow0 >= 0 || P.R % NB != 0 || P.Np > 65536 || P.R / NB >= 65536) return false;
+    if (dag_batch_route(P)) return !h->env.no_dag_batch && P.Np / NB >= h->env.dag_batch_min_nb;
+    return P.Np / NB >= h->env.dag_min_nb;
 }
 
-int dag_build(cgp_handle* h, long nb, long nr) {
+int dag_grid(cgp_handle* h) { return std::max(2, h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus); }
+
+void drop_graphs(cgp_handle* h) {
+    for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    h->graphs.clear();
+}
+
+// the list for `nmat` objects of nb x nr tiles (built and uploaded on first use; a few shapes stay cached)
+int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle::DagList** out, bool build) {
+    const CgpEnv& e = h->env;
+    DagSchedule sch;
+    if (batch) {
+        sch.depth = std::max(1l, e.dag_bdepth); sch.window = std::max(1l, e.dag_bwindow); sch.fill = 0.01 * e.dag_bfill;
+        sch.lead = e.dag_blead; sch.dmax = e.dag_bdmax; sch.slope = e.dag_bslope;
+    } else {
+        sch.depth = std::max(1l, e.dag_depth); sch.window = std::max(1l, e.dag_window); sch.fill = 0.01 * e.dag_fill;
+        sch.lead = e.dag_lead; sch.dmax = e.dag_dmax; sch.slope = e.dag_slope;
+    }
+    // the schedule's time budget per step is that of a whole GPU whatever the grid and the batch (an object's list must not
+    // depend on the number of objects beside it)
+    sch.workers = h->dag_cus - 1;
+    const int order = batch ? (int)e.dag_border : 0;
+    const long sig = ((((((sch.depth * 100 + sch.window) * 100 + sch.dmax) * 100 + sch.slope) * 1000 + (long)(sch.fill * 100)) * 10 + sch.lead) * 2 + order) * 2 + (batch ? 1 : 0);
+    for (auto& l : h->dag_lists)
+        if (l.nb == nb && l.nr == nr && l.nmat == nmat && l.sig == sig) { l.used = ++h->dag_clock; *out = &l; return 0; }
+    if (!build) return fail(h, CGP_E_STATE, "single-launch factorisation: task list missing");
+    if (h->dag_lists.size() >= 6) {
+        // evict the least recently used list; captured graphs may point to it
+        size_t v = 0;
+        for (size_t q = 1; q < h->dag_lists.size(); ++q) if (h->dag_lists[q].used < h->dag_lists[v].used) v = q;
+        HIPCHK(stream_sync(h));
+        drop_graphs(h);
+        free_buf(h->dag_lists[v].tasks);
+        h->dag_lists.erase(h->dag_lists.begin() + v);
+    }
+    std::vector<int4> t;
+    dag_build_tasks_batch(nb, nr, nmat, sch, t, order);
+    h->dag_lists.emplace_back();
+    cgp_handle::DagList& l = h->dag_lists.back();
+    CHK(ensure(h, l.tasks, t.size() * sizeof(int4)));
+    HIPCHK(hipMemcpyAsync(l.tasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(stream_sync(h));
+    l.nb = nb; l.nr = nr; l.nmat = nmat; l.sig = sig; l.ntasks = (int)t.size(); l.used = ++h->dag_clock;
+    if (e.debug) fprintf(stderr, "cgp: dag task list nb=%ld nr=%ld objects=%ld (%s): %d tasks\n", nb, nr, nmat, batch ? "batch" : "single", l.ntasks);
+    *out = &l;
+    return 0;
+}
+
+// objects per launch and number of launches for P
+void dag_groups(cgp_handle* h, const Prob& P, long& per, long& ngroups) {
+    // objects per launch: enough of them that the bulk updates of the others fill the chain-bound tail of each (about 512
+    // tile columns in flight), at most 16 leaf lanes
+    const long nb = P.Np / NB;
+    const long want = h->env.dag_bmax > 0 ? h->env.dag_bmax : std::max(4l, std::min(16l, 512 / std::max(1l, nb)));
+    per = dag_batch_route(P) ? std::min<long>(P.B, want) : 1;
+    per = std::min<long>(per, std::max(1, dag_grid(h) - 1));            // at least one worker lane
+    ngroups = (P.B + per - 1) / per;
+}
+
+size_t dag_state_words(long per, long nb, long nr) { return ((size_t)per * nr * nb + 3) / 4 * 4; }
+
+// everything a launch needs that cannot be done inside graph capture: lists, counters
+int dag_build(cgp_handle* h, const Prob& P) {
     if (!h->dag_cus) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, h->device));
         h->dag_cus = prop.multiProcessorCount;
     }
-    const int grid = std::max(2, h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus);
-    DagSchedule sch;
-    sch.depth = std::max<long>(1, h->env.dag_depth); sch.window = std::max<long>(1, h->env.dag_window);
-    sch.deep_min = h->env.dag_deep_min; sch.fill = 0.01 * h->env.dag_fill; sch.workers = grid - 1; sch.lead = h->env.dag_lead;
-    sch.dmax = h->env.dag_dmax; sch.slope = h->env.dag_slope;
-    const long depth = sch.depth, sig = ((((sch.depth * 100 + sch.window) * 100 + sch.dmax) * 100 + sch.slope) * 1000 + h->env.dag_fill) * 10 + sch.lead + 7 * grid;
-    if (h->dag_nb == nb && h->dag_nr == nr && h->dag_depth_built == sig) return 0;
-    std::vector<int4> t;
-    dag_build_tasks(nb, nr, sch, t);
-    CHK(ensure(h, h->dtasks, t.size() * sizeof(int4)));
-    CHK(h2d(h, h->dtasks.p, t.data(), t.size() * sizeof(int4)));
-    HIPCHK(stream_sync(h));
-    const size_t words = 8 + (size_t)nr * nb;
-    CHK(ensure(h, h->dstate, (words * sizeof(unsigned) + 15) / 16 * 16));
-    h->dag_ntasks = (int)t.size();
-    h->dag_nb = nb; h->dag_nr = nr; h->dag_depth_built = sig;
-    if (h->env.debug) fprintf(stderr, "cgp: dag task list nb=%ld nr=%ld depth=%ld: %d tasks\n", nb, nr, depth, h->dag_ntasks);
+    const long nb = P.Np / NB, nr = P.R / NB;
+    long per, ngroups;
+    dag_groups(h, P, per, ngroups);
+    cgp_handle::DagList* l;
+    CHK(dag_list(h, nb, nr, per, dag_batch_route(P), &l, true));
+    if (P.B % per) CHK(dag_list(h, nb, nr, P.B % per, dag_batch_route(P), &l, true));
+    const size_t words = (size_t)ngroups * (8 + dag_state_words(per, nb, nr));
+    if (h->dstate.cap < words * sizeof(unsigned)) {
+        HIPCHK(stream_sync(h));
+        drop_graphs(h);                 // captured launches point into the old buffer
+        CHK(ensure(h, h->dstate, words * sizeof(unsigned)));
+    }
     return 0;
 }
 
 int launch_dag(cgp_handle* h, Prob& P) {
     const long nb = P.Np / NB, nr = P.R / NB;
-    // (the list is built outside graph capture: device_fit calls dag_build before it starts capturing)
+    // (lists and counters come from dag_build, which device_fit calls before it starts capturing)
     static std::once_flag once_dev[64];
     static hipError_t err_dev[64];
     const int d = h->device & 63;
@@ -804,36 +885,47 @@ int launch_dag(cgp_handle* h, Prob& P) {
     });
     HIPCHK(err_dev[d]);
     StageScope sc(h, ST_DAG);
-    const size_t words = 8 + (size_t)nr * nb;
-    HIPCHK(hipMemsetAsync(h->dstate.p, 0, (words * sizeof(unsigned) + 15) / 16 * 16, h->stream));
-    DagParams dp;
-    dp.M = P.M; dp.ld = P.Np; dp.nb = (int)nb; dp.nr = (int)nr;
-    dp.tasks = (const int4*)h->dtasks.p; dp.ntasks = h->dag_ntasks;
-    dp.ctrl = (unsigned*)h->dstate.p; dp.state = (unsigned*)h->dstate.p + 8;
-    dp.wsW = P.wsW; dp.ldp = P.ldp; dp.info = P.info;
-    dp.timeout = (long long)h->env.dag_timeout_ms * 100000ll;           // wall_clock64 runs at 100 MHz
-    dp.dbg = 0;
-    dp.prof = nullptr;
-    const int grid = h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus;
-    hipLaunchKernelGGL(k_chol_dag, dim3((unsigned)std::max(2, grid)), dim3(DAG_THREADS), DAG_LDS_BYTES, h->stream, dp);
-    HIPCHK(hipGetLastError());
-    h->dag_ran = true;
+    long per, ngroups;
+    dag_groups(h, P, per, ngroups);
+    const size_t sw = dag_state_words(per, nb, nr);
+    HIPCHK(hipMemsetAsync(h->dstate.p, 0, (size_t)ngroups * (8 + sw) * sizeof(unsigned), h->stream));
+    for (long g = 0; g < ngroups; ++g) {
+        const long b0 = g * per, nmat = std::min(per, P.B - b0);
+        cgp_handle::DagList* l;
+        CHK(dag_list(h, nb, nr, nmat, dag_batch_route(P), &l, false));
+        DagParams dp;
+        dp.M = P.M + b0 * P.sM; dp.ld = P.Np; dp.nb = (int)nb; dp.nr = (int)nr;
+        dp.nmat = (int)nmat; dp.sM = P.sM; dp.sW = P.sW; dp.sLd = P.sLd;
+        dp.tasks = (const int4*)l->tasks.p; dp.ntasks = l->ntasks;
+        dp.ctrl = (unsigned*)h->dstate.p + 8 * g;
+        dp.state = (unsigned*)h->dstate.p + 8 * ngroups + g * sw;
+        dp.wsW = P.wsW + b0 * P.sW; dp.ldp = P.ldp + b0 * P.sLd; dp.info = P.info + b0;
+        dp.timeout = (long long)h->env.dag_timeout_ms * 100000ll;           // wall_clock64 runs at 100 MHz
+        dp.dbg = 0;
+        dp.prof = nullptr;
+        hipLaunchKernelGGL(k_chol_dag, dim3((unsigned)std::max<long>(dag_grid(h), nmat + 1)), dim3(DAG_THREADS), DAG_LDS_BYTES, h->stream, dp);
+        HIPCHK(hipGetLastError());
+        if (h->profiling) h->gemm_launches++;          // stage report [6]: launches of the dominant kernel
+    }
+    h->dag_groups_ran = ngroups;
     return 0;
 }
 
-// after a synchronised fit: did the single-launch factorisation give up (bounded spins)?
+// after a synchronised fit: did a single-launch factorisation give up (bounded spins)?
 int dag_check(cgp_handle* h) {
-    if (!h->dag_ran) return 0;
-    h->dag_ran = false;
-    unsigned c[4] = {0, 0, 0, 0};
-    CHK(d2h(h, c, h->dstate.p, sizeof(c)));
+    if (!h->dag_groups_ran) return 0;
+    const long ng = h->dag_groups_ran;
+    h->dag_groups_ran = 0;
+    std::vector<unsigned> c((size_t)ng * 8, 0u);
+    CHK(d2h(h, c.data(), h->dstate.p, c.size() * sizeof(unsigned)));
     HIPCHK(stream_sync(h));
-    if (c[1] != 0) {
-        char msg[160];
-        snprintf(msg, sizeof(msg), "single-launch factorisation gave up (abort %u, wait code 0x%x, ticket %u of %d, leaf stamp %u)",
-                 c[1], c[2], c[0], h->dag_ntasks, c[3]);
-        return fail(h, CGP_E_HIP, msg);
-    }
+    for (long g = 0; g < ng; ++g)
+        if (c[8 * g + 1] != 0) {
+            char msg[200];
+            snprintf(msg, sizeof(msg), "single-launch factorisation gave up (launch %ld of %ld: abort %u, wait code 0x%x, ticket %u, leaf stamp %u)",
+                     g, ng, c[8 * g + 1], c[8 * g + 2], c[8 * g], c[8 * g + 3]);
+            return fail(h, CGP_E_HIP, msg);
+        }
     return 0;
 }
 
@@ -878,7 +970,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
 // call instead of 200.  Everything that changes between calls (kernel parameters, kss_noise,
 // diagonal, coordinates) lives in HBM buffers the graph only points to.
 int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
-    if (dag_eligible(h, P)) CHK(dag_build(h, P.Np / NB, P.R / NB));     // (not capturable: host copy + synchronise)
+    if (dag_eligible(h, P)) CHK(dag_build(h, P));     // (not capturable: host copy + synchronise)
     if (!h->use_graph || h->profiling || h->env.no_graph) return device_fit_eager(h, P, m, has_mean);
     cgp_handle::GraphKey key;
     std::memset(&key, 0, sizeof(key));

@@ -1,13 +1,16 @@
-// Single-launch blocked Cholesky of ONE object (gfx950): a persistent grid, one 512-thread workgroup per CU, that walks
-// the tile DAG of the right-looking factorisation with dependency counters in HBM instead of kernel boundaries.
+// Single-launch blocked Cholesky of one object, or of `nmat` same-shape objects side by side (gfx950): a persistent grid,
+// one 512-thread workgroup per CU, that walks the tile DAG of the right-looking factorisation with dependency counters in
+// HBM instead of kernel boundaries.  With several objects every object has its own leaf lane (workgroup b for object b),
+// counters and buffers (constant strides); the workers serve ONE list in which the objects' lists are interleaved step by
+// step, so the chain-bound tail of one object is filled with the bulk updates of the others.
 //
 //   tiles           128 x 128 (CGP_NB); row tiles i = 0 .. nr-1 (the tall rows of the fit included), column tiles
 //                   ("panels") k = 0 .. nb-1
-//   leaf lane       workgroup 0 only.  For k = 0, 1, ...: factor the diagonal tile (k, k) in LDS (potrf128_lds, the K3
+//   leaf lane       workgroup b < nmat, for object b.  For k = 0, 1, ...: factor the diagonal tile (k, k) in LDS (potrf128_lds, the K3
 //                   code), solve the tile below it, X = A(k+1, k) L_kk^-T, with the factor still in LDS (the K4 code),
 //                   and apply X X^T to the next diagonal tile, again in LDS: the critical chain of the factorisation never
 //                   leaves this CU and never waits for a launch.
-//   worker lanes    workgroups 1 .. G-1 take tasks from ONE list in ticket order (a device-scope atomic):
+//   worker lanes    workgroups nmat .. G-1 take tasks from ONE list in ticket order (a device-scope atomic):
 //                     TRSM(i, k)          X = A(i, k) L_kk^-T                         for i >= k + 2
 //                     UPD(i, j, k0, k1)   A(i, j) -= sum_{k0 <= k < k1} L(i, k) L(j, k)^T
 //                   Every dependency of a task sits EARLIER in the list (or on the leaf lane, whose own dependencies sit
@@ -34,10 +37,12 @@ struct DagParams {
     double* M;              // the fit's matrix buffer (rows [0, Np): K -> L, rows [Np, R): tall rows)
     long ld;                // leading dimension = Np
     int nb, nr;             // column tiles, row tiles
-    const int4* tasks;      // {i, j, k0, (k1 << 1) | type}   type 0 = TRSM (panel j), 1 = UPD
+    int nmat;               // objects factored side by side (leaf lanes); object b: M + b sM, wsW + b sW, ldp + b sLd, info + b,
+    long sM, sW, sLd;       //   state + b nr nb
+    const int4* tasks;      // {i | (object << 16), j, k0, (k1 << 1) | type}   type 0 = TRSM (panel j), 1 = UPD
     int ntasks;
-    unsigned* state;        // [nr * nb]
-    unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)
+    unsigned* state;        // [nmat][nr * nb]
+    unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)  [3] progress of leaf lane 0
     double* wsW;            // [nb][8][256] T^-T blocks of the diagonal tiles (also read by later solves)
     double* ldp;            // [nb] logdet parts
     int* info;
@@ -176,24 +181,30 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
     const __amdgpu_buffer_rsrc_t ra_ = dag_rsrc(Ag), rb_ = dag_rsrc(Bg), rc_ = dag_rsrc(Cg);
     const unsigned ldb = (unsigned)(ld * 8);
 
-    double acc[MT][NJ];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.;
-    // C values of this lane, fetched before the K loop: acc[i][2 jj], acc[i][2 jj + 1] <-> row 64 wm + 16 i + 4 lb + lq,
-    // columns 32 wn + 8 jj + 2 lp + (0, 1)
+    // The accumulators start from -C and the result is stored negated: C - sum A B^T without a second copy of the tile in
+    // registers (sign changes are exact, so this is the same rounding sequence as accumulating onto +C with -A).
+    // acc[i][2 jj], acc[i][2 jj + 1] <-> row 64 wm + 16 i + 4 lb + lq, columns 32 wn + 8 jj + 2 lp + (0, 1)
     const unsigned coff = (unsigned)(wm * 64 + 4 * lb + lq) * ldb + (unsigned)(wn * 32 + 2 * lp) * 8u;
-    d2 cv[MT][NJ / 2];
+    double acc[MT][NJ];
+    {
+        d2 cv[MT][NJ / 2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int jj = 0; jj < NJ / 2; ++jj) cv[i][jj] = ldc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u);
+            for (int jj = 0; jj < NJ / 2; ++jj) cv[i][jj] = ldc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ / 2; ++jj) { acc[i][2 * jj] = -cv[i][jj].x; acc[i][2 * jj + 1] = -cv[i][jj].y; }
+    }
 
     d2 ra[2][PA], rb[2][PB];
     const int nk = K / KB;
     auto gload = [&](auto par, int kt) {
         constexpr int P = decltype(par)::value;
+#if defined(DAG_ABLATE) && (DAG_ABLATE == 1 || DAG_ABLATE == 3)
+        if (kt > 1) return;             // timing experiment (tools/dag_probe.hip): no global loads inside the loop
+#endif
         const unsigned k1 = (unsigned)(kt * KB + sch) * 8u;
 #pragma unroll
         for (int q = 0; q < PA; ++q) ra[P][q] = ldc2(ra_, (unsigned)(srow + RSTEP * q) * ldb + k1);
@@ -207,25 +218,49 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
 #pragma unroll
         for (int q = 0; q < PB; ++q) *(d2*)(&Bs[buf * TN * KS + (srow + RSTEP * q) * KS + sch]) = rb[P][q];
     };
-    auto compute = [&](int cur) {
-        d2 fa[MT], fb[NJ];
+    // fragments of half a stage (8 of its 16 k): two register sets, the reads of one half are issued among the MFMAs of the
+    // half before it
+    d2 fa[2][MT], fb[2][NJ];
+#if defined(DAG_ABLATE) && DAG_ABLATE >= 2
 #pragma unroll
-        for (int t = 0; t < KB / 8; ++t) {
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = *(const d2*)(&As[cur * TM * KS + (wm * 64 + i * 16 + lr) * KS + 8 * t + 2 * lq]);
+        for (int i = 0; i < MT; ++i) fa[q][i] = (d2){(double)(lane + i), (double)(q + 1)};
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                fb[j] = *(const d2*)(&Bs[cur * TN * KS + (wn * 32 + 8 * (j >> 1) + 2 * lp + (j & 1)) * KS + 8 * t + 2 * lq]);
+        for (int j = 0; j < NJ; ++j) fb[q][j] = (d2){(double)(lane - j), (double)(q + 2)};
+    }
+#endif
+    auto fread = [&](auto setc, int buf, int t) {
+        constexpr int S = decltype(setc)::value;
+#if defined(DAG_ABLATE) && DAG_ABLATE >= 2
+        if (buf + t >= 0) return;       // timing experiment (tools/dag_probe.hip): no fragment reads
+#endif
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
+            fa[S][i] = *(const d2*)(&As[buf * TM * KS + (wm * 64 + i * 16 + lr) * KS + 8 * t + 2 * lq]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].x, fb[j].x, acc[i][j]);
+        for (int j = 0; j < NJ; ++j)
+            fb[S][j] = *(const d2*)(&Bs[buf * TN * KS + (wn * 32 + 8 * (j >> 1) + 2 * lp + (j & 1)) * KS + 8 * t + 2 * lq]);
+    };
+    auto fmma = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[i].y, fb[j].y, acc[i][j]);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[S][i].x, fb[S][j].x, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(fa[S][i].y, fb[S][j].y, acc[i][j]);
+    };
+    // issue order asked of the scheduler for {12 LDS reads, 64 MFMAs}: one read every five MFMAs
+    auto interleave_reads = [&]() {
+#pragma unroll
+        for (int r = 0; r < MT + NJ; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
@@ -234,25 +269,40 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
     __builtin_amdgcn_sched_barrier(0);
     lstore(P0{}, 0);
     __syncthreads();
+    fread(P0{}, 0, 0);
     for (int kt = 0; kt < nk; kt += 2) {
+        // stage in buffer 0; stage kt + 1 goes to buffer 1 meanwhile
         gload(P0{}, min(kt + 2, nk - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0);
+        fread(P1{}, 0, 1);
+        fmma(P0{});
         lstore(P1{}, 1);
-        __syncthreads();
+        __builtin_amdgcn_sched_group_barrier(0x020, PA + PB, 0);
+        interleave_reads();
+        __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);
+        __syncthreads();                 // buffer 1 complete; every wave's reads of buffer 0 have returned
+        fread(P0{}, 1, 0);
+        fmma(P1{});
+        // stage in buffer 1; stage kt + 2 goes to buffer 0 meanwhile
         gload(P1{}, min(kt + 3, nk - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
+        fread(P1{}, 1, 1);
+        fmma(P0{});
         lstore(P0{}, 0);
+        interleave_reads();
+        __builtin_amdgcn_sched_group_barrier(0x020, PA + PB, 0);
+        interleave_reads();
+        __builtin_amdgcn_sched_group_barrier(0x200, PA + PB, 0);
         __syncthreads();
+        fread(P0{}, 0, 0);
+        fmma(P1{});
+        interleave_reads();
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jj = 0; jj < NJ / 2; ++jj) {
             d2 o;
-            o.x = cv[i][jj].x - acc[i][2 * jj];
-            o.y = cv[i][jj].y - acc[i][2 * jj + 1];
+            o.x = -acc[i][2 * jj];
+            o.y = -acc[i][2 * jj + 1];
             stc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u, o);
         }
 }
@@ -547,13 +597,19 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
     return 1;
 }
 
-__device__ void dag_leaf(const DagParams& p, double* smem) {
+__device__ void dag_leaf(const DagParams& p, double* smem, int b) {
     double* As = smem;
     const int tid = threadIdx.x;
     const unsigned ldb = (unsigned)(p.ld * 8);
+    double* const M = p.M + (long)b * p.sM;
+    unsigned* const state = p.state + (long)b * p.nr * p.nb;
+    double* const wsW = p.wsW + (long)b * p.sW;
+    double* const ldp = p.ldp + (long)b * p.sLd;
+    int* const info = p.info + b;
+    unsigned long long* const prof = b == 0 ? p.prof : nullptr;
     {
         // tile (0, 0) as assembled, straight into LDS (tiles on and below the block diagonal)
-        const __amdgpu_buffer_rsrc_t rd = dag_rsrc(p.M);
+        const __amdgpu_buffer_rsrc_t rd = dag_rsrc(M);
         constexpr int NCH = CGP_NB * 64 / DAG_THREADS;      // 16
         d2 v[NCH];
 #pragma unroll
@@ -569,17 +625,17 @@ __device__ void dag_leaf(const DagParams& p, double* smem) {
         __syncthreads();
     }
     for (int k = 0; k < p.nb; ++k) {
-        dag_stamp(p.ctrl, 4u * k + 1u);
+        if (b == 0) dag_stamp(p.ctrl, 4u * k + 1u);
         if (p.dbg == 1) return;
-        if (p.prof && tid == 0) p.prof[k * 8 + 0] = wall_clock64();
+        if (prof && tid == 0) prof[k * 8 + 0] = wall_clock64();
         const int bad = dag_potrf_call();
-        if (p.prof && tid == 0) p.prof[k * 8 + 1] = wall_clock64();
-        dag_stamp(p.ctrl, 4u * k + 2u);
+        if (prof && tid == 0) prof[k * 8 + 1] = wall_clock64();
+        if (b == 0) dag_stamp(p.ctrl, 4u * k + 2u);
         if (p.dbg == 2) return;
-        if (dag_leaf_step(p.M, p.ld, p.nb, p.nr, p.state, p.ctrl, p.timeout, p.wsW, p.ldp, p.info, k, bad,
-                          p.prof ? p.prof + k * 8 + 2 : nullptr) != 1) break;
+        if (dag_leaf_step(M, p.ld, p.nb, p.nr, state, p.ctrl, p.timeout, wsW, ldp, info, k, bad,
+                          prof ? prof + k * 8 + 2 : nullptr) != 1) break;
     }
-    dag_stamp(p.ctrl, 0xffffu);
+    if (b == 0) dag_stamp(p.ctrl, 0xffffu);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -588,38 +644,41 @@ __device__ void dag_leaf(const DagParams& p, double* smem) {
 __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int* cw = (int*)(smem + DAG_LDS_DOUBLES);       // [0] wait result, [1..5] ticket + descriptor
-    if (blockIdx.x == 0) {
-        if (p.dbg != 9) dag_leaf(p, smem);          // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
+    if ((int)blockIdx.x < p.nmat) {
+        if (p.dbg != 9) dag_leaf(p, smem, (int)blockIdx.x);   // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
         return;
     }
     const int nb = p.nb;
+    const long sS = (long)p.nr * nb;
     if (p.dbg != 0 && p.dbg < 5) return;
     long long acc_wait = 0, acc_trsm = 0, acc_upd = 0, acc_n = 0, tm0 = 0, tm1 = 0, acc_wt = 0, acc_w1 = 0;
     for (;;) {
         if (p.prof) tm0 = wall_clock64();
         const int t = __builtin_amdgcn_readfirstlane(dag_fetch(p.ctrl, p.tasks, p.ntasks));
         if (t >= p.ntasks) break;
-        const int i = __builtin_amdgcn_readfirstlane(cw[2]), j = __builtin_amdgcn_readfirstlane(cw[3]);
+        const int ib = __builtin_amdgcn_readfirstlane(cw[2]), j = __builtin_amdgcn_readfirstlane(cw[3]);
         const int k0 = __builtin_amdgcn_readfirstlane(cw[4]), w = __builtin_amdgcn_readfirstlane(cw[5]);
-        const int type = w & 1, k1 = w >> 1;
+        const int type = w & 1, k1 = w >> 1, i = ib & 0xffff, ob = ib >> 16;
+        unsigned* const state = p.state + (long)ob * sS;
+        double* const M = p.M + (long)ob * p.sM;
         if (type == 0) {
             // TRSM(i, k = j): needs the factor of (k, k) and every update of (i, k)
-            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 2, p.state + (long)j * nb + j, (unsigned)(j + 1),
-                                                         p.state + (long)i * nb + j, (unsigned)j, nullptr, 0, 0x30000 + t))) break;
+            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 2, state + (long)j * nb + j, (unsigned)(j + 1),
+                                                         state + (long)i * nb + j, (unsigned)j, nullptr, 0, 0x30000 + t))) break;
             if (p.prof) tm1 = wall_clock64();
-            if (p.dbg != 5 && p.dbg != 7) dag_trsm_task(p.M, p.ld, p.wsW, i, j);
-            dag_publish(p.state + (long)i * nb + j, (unsigned)(j + 1));
+            if (p.dbg != 5 && p.dbg != 7) dag_trsm_task(M, p.ld, p.wsW + (long)ob * p.sW, i, j);
+            dag_publish(state + (long)i * nb + j, (unsigned)(j + 1));
             if (p.prof) { acc_wait += tm1 - tm0; acc_wt += tm1 - tm0; acc_trsm += wall_clock64() - tm1; ++acc_n; }
         } else {
             // UPD(i, j, k0, k1): panels k0..k1-1 of rows i and j final, tile (i, j) updated through k0-1
-            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 3, p.state + (long)i * nb + (k1 - 1), (unsigned)k1,
-                                                         p.state + (long)j * nb + (k1 - 1), (unsigned)k1, p.state + (long)i * nb + j,
+            if (!__builtin_amdgcn_readfirstlane(dag_wait(p.ctrl, p.timeout, 3, state + (long)i * nb + (k1 - 1), (unsigned)k1,
+                                                         state + (long)j * nb + (k1 - 1), (unsigned)k1, state + (long)i * nb + j,
                                                          (unsigned)k0, 0x40000 + t))) break;
             if (p.prof) tm1 = wall_clock64();
             if (p.dbg != 5 && p.dbg != 6)
-                dag_upd_tile(p.M + (long)(i * CGP_NB) * p.ld + (long)j * CGP_NB, p.M + (long)(i * CGP_NB) * p.ld + (long)k0 * CGP_NB,
-                             p.M + (long)(j * CGP_NB) * p.ld + (long)k0 * CGP_NB, p.ld, (k1 - k0) * CGP_NB);
-            dag_publish(p.state + (long)i * nb + j, (unsigned)k1);
+                dag_upd_tile(M + (long)(i * CGP_NB) * p.ld + (long)j * CGP_NB, M + (long)(i * CGP_NB) * p.ld + (long)k0 * CGP_NB,
+                             M + (long)(j * CGP_NB) * p.ld + (long)k0 * CGP_NB, p.ld, (k1 - k0) * CGP_NB);
+            dag_publish(state + (long)i * nb + j, (unsigned)k1);
             if (p.prof) { acc_wait += tm1 - tm0; if (k1 - k0 == 1) acc_w1 += tm1 - tm0; acc_upd += wall_clock64() - tm1; ++acc_n; }
         }
     }

@@ -36,7 +36,9 @@ struct DagSchedule {
     double step_us = 58., task_us = 10., panel_us = 17., trsm_us = 16., fill = 0.7;
 };
 
-inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector<int4>& t) {
+// `steps` (optional) receives the segment boundaries of the list: [0] = 0, [1] = end of the solves of panel 0, then three per
+// step k: end of the updates of column k+1, end of the look-ahead solves of panel k+1, end of the step.
+inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector<int4>& t, std::vector<size_t>* steps = nullptr) {
     const long window = std::max<long>(1, sc.window), depth = std::max<long>(1, sc.depth), dmax = std::max(depth, sc.dmax);
     t.clear();
     std::vector<long> applied((size_t)nr * nb, 0);         // panels already scheduled onto tile (i, j)
@@ -53,13 +55,17 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
         return true;
     };
     auto column = [&](long k, long j, long cap) { for (long i = j; i < nr; ++i) tile(k, i, j, cap); };
+    if (steps) steps->assign(1, 0);
     for (long i = 2; i < nr; ++i) t.push_back(make_int4((int)i, 0, 0, 0));
+    if (steps) steps->push_back(t.size());
     for (long k = 0; k < nb; ++k) {
+        if (k > 0 && steps) steps->push_back(t.size());
         spent = 0.;
-        if (k + 1 < nb) {
-            column(k, k + 1, nb);
+        if (k + 1 < nb) column(k, k + 1, nb);
+        if (steps) steps->push_back(t.size());
+        if (k + 1 < nb)
             for (long i = k + 3; i < nr; ++i) { t.push_back(make_int4((int)i, (int)(k + 1), 0, 0)); spent += sc.trsm_us; }
-        }
+        if (steps) steps->push_back(t.size());
         for (long j = k + 2; j < nb && j <= k + window; ++j) column(k, j, nb);
         if (depth == 1) {
             for (long j = k + window + 1; j < nb; ++j) column(k, j, nb);
@@ -75,5 +81,36 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
         for (long j = k + window + 1; j < nb && spent < budget; ++j)
             for (long i = j; i < nr && spent < budget; ++i)
                 if (k + 1 - applied[(size_t)i * nb + j] >= depth) tile(k, i, j, dmax);
+    }
+    if (steps) steps->push_back(t.size());
+}
+
+// The list for `nmat` same-shape objects: the single-object list of every object (object index in the upper half of .x),
+// interleaved step by step.  Per step: every object's updates of column k+1 (they release the leaf lanes), then every
+// object's remaining updates, then every object's look-ahead solves of panel k+1 -- by then the leaf lanes have factored
+// their diagonal tiles, so no worker sits in a solve waiting for a factor while other objects have work (order = 0 keeps the
+// single-object order inside a step: solves before the remaining updates).  The solves of panel k+1 and the updates with
+// panel k touch different tiles, so moving one behind the other keeps every dependency pointing backwards; every tile sees
+// its updates in the same order and the same grouping as in the single-object list, so an object's arithmetic does not
+// depend on `nmat`.
+inline void dag_build_tasks_batch(long nb, long nr, long nmat, const DagSchedule& sc, std::vector<int4>& t, int order = 1) {
+    std::vector<int4> one;
+    std::vector<size_t> m;
+    dag_build_tasks(nb, nr, sc, one, &m);
+    t.clear();
+    t.reserve(one.size() * (size_t)nmat);
+    auto emit = [&](size_t lo, size_t hi) {
+        for (long b = 0; b < nmat; ++b)
+            for (size_t q = lo; q < hi; ++q) {
+                int4 d = one[q];
+                d.x |= (int)(b << 16);
+                t.push_back(d);
+            }
+    };
+    emit(m[0], m[1]);
+    for (size_t s = 1; s + 3 < m.size(); s += 3) {
+        // segments [m[s], m[s+1]) column k+1, [m[s+1], m[s+2]) solves, [m[s+2], m[s+3]) the rest
+        if (order == 0 || nmat == 1) emit(m[s], m[s + 3]);
+        else { emit(m[s], m[s + 1]); emit(m[s + 2], m[s + 3]); emit(m[s + 1], m[s + 2]); }
     }
 }

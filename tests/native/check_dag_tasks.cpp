@@ -12,8 +12,16 @@ int main(int argc, char** argv) {
                         for (double fill : {0.3, 1.0, 2.0}) {
                             DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4; sc.dmax = depth + (window % 3) * 4; sc.slope = 1 + dm / 20;
                             const long nr = nb + tall;
+                            // several objects side by side (every object is checked with its own counters and leaf lane),
+                            // both interleaving orders
+                            for (int variant = 0; variant < (nb <= 32 ? 3 : 1); ++variant) {
+                            const long nmat = variant == 0 ? 1 : 3;
+                            std::vector<int4> tall_list;
+                            dag_build_tasks_batch(nb, nr, nmat, sc, tall_list, variant == 2 ? 0 : 1);
+                            if (nmat == 1) { std::vector<int4> ref; dag_build_tasks(nb, nr, sc, ref); if (ref.size() != tall_list.size()) { printf("SIZE MISMATCH\n"); ++bad; } }
+                            for (long ob = 0; ob < nmat; ++ob) {
                             std::vector<int4> t;
-                            dag_build_tasks(nb, nr, sc, t);
+                            for (const int4& d : tall_list) if ((d.x >> 16) == ob) { int4 e = d; e.x &= 0xffff; t.push_back(e); }
                             std::vector<int> state(nr * nb, 0);       // simulated in list order with the leaf lane as far ahead as it can be
                             int leaf_k = 0;                            // leaf has finished potrf(leaf_k - 1) and near trsm
                             // the leaf lane exactly as dag_leaf_step orders its waits and publishes (sub = how far step leaf_k got)
@@ -58,6 +66,8 @@ int main(int argc, char** argv) {
                             leaf_advance();
                             if (ok) for (long i = 0; i < nr; ++i) for (long j = 0; j < nb && j <= i; ++j) if (state[i * nb + j] != j + 1) { ok = false; printf("INCOMPLETE nb=%ld tall=%ld d=%ld w=%ld dm=%ld tile (%ld,%ld) state %d\n", nb, tall, depth, window, dm, i, j, state[i * nb + j]); break; }
                             bad += !ok;
+                            }
+                            }
                         }
     printf("%d bad configurations\n", bad);
     return bad != 0;

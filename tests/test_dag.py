@@ -108,3 +108,83 @@ def test_dag_c3_size(monkeypatch):
     a = _fit({}, monkeypatch, 2, x, y, e, xn)[0]
     b = _fit({'CGP_NO_DAG': '1'}, monkeypatch, 2, x, y, e, xn)[0]
     _close(a, b, 1e-11)
+
+
+# ---- several objects per launch (the batched entry points from 16 tile columns on; forced here for small objects) ------------
+
+def _batch(env, monkeypatch, xs, ys, es, xn, chunks=None):
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    for k in ('CGP_NO_DAG', 'CGP_NO_DAG_BATCH', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_DAG_GRID', 'CGP_NO_GRAPH'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = _lib.Device(0)
+    kp = K.kernel_params_1d([1., 2.])
+    chunks = chunks or [list(range(len(xs)))]
+    ll, info, mu, var = [], [], [], []
+    for c in chunks:
+        o = dev.batch_fit(1, [xs[i] for i in c], [ys[i] for i in c], [K.diag_term(len(ys[i]), es[i], 0., 0.) for i in c], kp, xn, None, 0.)
+        ll.append(o[0]); info.append(o[1]); mu.append(o[2]); var.append(o[3])
+    dev.close()
+    return np.concatenate(ll), np.concatenate(info), np.concatenate(mu), np.concatenate(var)
+
+
+def test_dag_batch_equals_launch_route_oracle_and_any_chunking(monkeypatch):
+    """Seven ragged objects (300..640 points, padded to 640 = 5 tile columns) through cgp_batch_fit on the single-launch
+    route: equal to the launch-per-step route to rounding and to the oracle; bit-identical however the batch is cut into
+    calls and launches (CGP_DAG_BMAX = objects per launch), with 3 workgroups (fewer workers than objects need) and eagerly."""
+    rng = np.random.default_rng(5)
+    ns = [640, 300, 513, 640, 384, 601, 450]
+    probs = [_problem(n, 0, 900 + i) for i, n in enumerate(ns)]
+    xs, ys, es = [p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs]
+    xn = rng.uniform(0., 40., 70)
+    force = {'CGP_DAG_BATCH_MIN_NB': '2'}
+    ref = _batch(force, monkeypatch, xs, ys, es, xn)
+    steps = _batch({'CGP_NO_DAG_BATCH': '1'}, monkeypatch, xs, ys, es, xn)
+    assert not ref[1].any() and not steps[1].any()
+    np.testing.assert_allclose(ref[0], steps[0], rtol=1e-12)
+    np.testing.assert_allclose(ref[2], steps[2], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(ref[3], steps[3], rtol=0, atol=1e-10)
+    for i in (1, 5):
+        Kc = orc.rbf_kernel_1d(xs[i], [1., 2.], y_err=es[i])
+        mu, var, ll = orc.fit_predict_cho(Kc, ys[i], orc.rbf_kernel_1d(xs[i], [1., 2.], new_x=xn), np.full(len(xn), 1.))
+        assert abs(ref[0][i] - ll) <= 1e-11 * abs(ll)
+        np.testing.assert_allclose(ref[2][i], mu, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ref[3][i], var, rtol=0, atol=1e-9)
+    variants = [dict(force, CGP_DAG_BMAX='2'), dict(force, CGP_DAG_BMAX='3', CGP_DAG_GRID='5'), dict(force, CGP_NO_GRAPH='1')]
+    for env in variants:
+        got = _batch(env, monkeypatch, xs, ys, es, xn)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), env
+    # the objects one by one: every object alone has 3..5 tile columns of its own (its padding differs from the batch's), so
+    # only objects of the batch's full width are bit-identical to their solo run
+    solo = _batch(force, monkeypatch, xs, ys, es, xn, chunks=[[i] for i in range(len(ns))])
+    for i, n in enumerate(ns):
+        if n > 512:
+            assert solo[0][i] == ref[0][i] and np.array_equal(solo[2][i], ref[2][i]) and np.array_equal(solo[3][i], ref[3][i])
+        else:
+            assert abs(solo[0][i] - ref[0][i]) <= 1e-12 * abs(ref[0][i])
+    cut = _batch(force, monkeypatch, xs, ys, es, xn, chunks=[[0, 3, 5], [1], [2, 4, 6]])
+    # (a chunk of narrower objects is padded less: same numbers to rounding there, bit-identical where the width is the same)
+    assert np.array_equal(cut[0][:3], ref[0][[0, 3, 5]]) and np.array_equal(cut[2][:3], ref[2][[0, 3, 5]])
+
+
+def test_dag_batch_reports_the_failing_object(monkeypatch):
+    """A non-positive-definite object inside a batch on the single-launch route: its info word is set (LAPACK's leading
+    minor), the other objects of the launch are untouched."""
+    probs = [_problem(384, 0, 70 + i) for i in range(4)]
+    xs, ys, es = [p[0] for p in probs], [p[1] for p in probs], [p[2].copy() for p in probs]
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    monkeypatch.setenv('CGP_DAG_BATCH_MIN_NB', '2')
+    dev = _lib.Device(0)
+    kp = K.kernel_params_1d([1., 2.])
+    diags = [K.diag_term(384, e, 0., 0.) for e in es]
+    good = dev.batch_fit(1, xs, ys, diags, kp, None, None, 0.)
+    diags[2] = diags[2].copy()
+    diags[2][200] = -5.0                       # K[200, 200] = 1 - 5 < 0
+    bad = dev.batch_fit(1, xs, ys, diags, kp, None, None, 0.)
+    dev.close()
+    assert not good[1].any()
+    assert bad[1][2] == 201 and not bad[1][[0, 1, 3]].any()
+    assert np.array_equal(bad[0][[0, 1, 3]], good[0][[0, 1, 3]])

@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     if (argc > 8) sch.fill = 0.01 * atoi(argv[8]);
     if (argc > 9) sch.lead = atoi(argv[9]);
     if (argc > 10) sch.slope = atoi(argv[10]);
+    const int nmat = getenv("DAG_PROBE_NMAT") ? atoi(getenv("DAG_PROBE_NMAT")) : 1;      // objects side by side (same matrix in each)
     const int nb = n / 128, nr = nb + tall;
     const long ld = n, R = (long)nr * 128;
     std::vector<double> A((size_t)R * ld, 0.);
@@ -25,7 +26,8 @@ int main(int argc, char** argv) {
         for (int j = 0; j < n; ++j) A[(size_t)i * ld + j] = (i == j ? 2.0 : 0.) + 0.5 * std::exp(-0.001 * (i - j) * (i - j));
     for (int j = 0; j < n; ++j) A[(size_t)(R - 1) * ld + j] = std::sin(0.1 * j);          // residual row
     std::vector<int4> t;
-    dag_build_tasks(nb, nr, sch, t);
+    sch.workers = getenv("DAG_PROBE_SCHED_WORKERS") ? atoi(getenv("DAG_PROBE_SCHED_WORKERS")) : grid - 1;
+    dag_build_tasks_batch(nb, nr, nmat, sch, t, getenv("DAG_PROBE_ORDER") ? atoi(getenv("DAG_PROBE_ORDER")) : 1);
     if (dbg == 9) {
         // update-task benchmark: every lower tile once, depth `depth` (k0 = 0), all dependencies pre-satisfied
         t.clear();
@@ -34,14 +36,15 @@ int main(int argc, char** argv) {
                 for (int j = depth; j <= i && j < nb; ++j) t.push_back(make_int4(i, j, 0, (depth << 1) | 1));
     }
     double *dA, *dW, *dL; int4* dT; unsigned* dS; int* dI;
-    CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dW, (size_t)nb * 2048 * 8)); CK(hipMalloc(&dL, nb * 8));
-    CK(hipMalloc(&dT, (t.size() + 1) * sizeof(int4))); CK(hipMalloc(&dS, (8 + nr * nb) * 4 + 64)); CK(hipMalloc(&dI, 64));
-    CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dA, A.size() * 8 * nmat)); CK(hipMalloc(&dW, (size_t)nb * 2048 * 8 * nmat)); CK(hipMalloc(&dL, nb * 8 * nmat));
+    CK(hipMalloc(&dT, (t.size() + 1) * sizeof(int4))); CK(hipMalloc(&dS, (8 + (size_t)nr * nb * nmat) * 4 + 64)); CK(hipMalloc(&dI, 64 + 4 * nmat));
+    for (int b = 0; b < nmat; ++b) CK(hipMemcpy(dA + (size_t)b * A.size(), A.data(), A.size() * 8, hipMemcpyHostToDevice));
     if (!t.empty()) CK(hipMemcpy(dT, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice));
-    CK(hipMemset(dS, 0, (8 + nr * nb) * 4 + 64)); CK(hipMemset(dI, 0, 64));
+    CK(hipMemset(dS, 0, (8 + (size_t)nr * nb * nmat) * 4 + 64)); CK(hipMemset(dI, 0, 64 + 4 * nmat));
     if (dbg == 9) { std::vector<unsigned> big(nr * nb, 100000u); CK(hipMemcpy(dS + 8, big.data(), big.size() * 4, hipMemcpyHostToDevice)); }
     CK(hipFuncSetAttribute((const void*)k_chol_dag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES));
     DagParams p;
+    p.nmat = dbg == 9 ? 1 : nmat; p.sM = (long)A.size(); p.sW = (long)nb * 2048; p.sLd = nb;
     p.M = dA; p.ld = ld; p.nb = nb; p.nr = nr; p.tasks = dT; p.ntasks = (int)t.size(); p.ctrl = dS; p.state = dS + 8;
     unsigned long long* dP; const size_t nprof = (size_t)nb * 8 + (size_t)grid * 4 + 8;
     CK(hipMalloc(&dP, nprof * 8)); CK(hipMemset(dP, 0, nprof * 8));
@@ -68,7 +71,7 @@ int main(int argc, char** argv) {
             printf("\n"); fflush(stdout);
             _exit(4);
         }
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
     unsigned c[4]; CK(hipMemcpy(c, dS, 16, hipMemcpyDeviceToHost));
@@ -86,8 +89,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     std::vector<unsigned> stt(nr * nb); CK(hipMemcpy(stt.data(), dS + 8, nr * nb * 4, hipMemcpyDeviceToHost));
-    printf("done: ticket %u abort %u code 0x%x stamp %u; states:", c[0], c[1], c[2], c[3]);
-    for (unsigned v : stt) printf(" %u", v);
+    printf("done in %.3f ms (host wall): ticket %u abort %u code 0x%x stamp %u", wall_ms, c[0], c[1], c[2], c[3]);
+    if (nr * nb <= 64) { printf("; states:"); for (unsigned v : stt) printf(" %u", v); }
     printf("\n");
     if (dbg == 0) {
         std::vector<unsigned long long> pr(nprof); CK(hipMemcpy(pr.data(), dP, nprof * 8, hipMemcpyDeviceToHost));
@@ -101,6 +104,11 @@ int main(int argc, char** argv) {
             ph[3] += (q[4] - q[3]) * us;        // solve, X published
             ph[4] += (q[5] - q[4]) * us;        // X X^T update into LDS
             ph[6] += (pr[(size_t)(k + 1) * 8] - q[0]) * us;   // whole step
+        }
+        if (getenv("DAG_PROBE_STEPS")) {
+            printf("step durations (us), 8 per row:");
+            for (int k = 0; k + 1 < nb; ++k) printf("%s%6.1f", k % 8 == 0 ? "\n  " : " ", (pr[(size_t)(k + 1) * 8] - pr[(size_t)k * 8]) * us);
+            printf("\n");
         }
         const double total = (pr[(size_t)(nb - 1) * 8 + 3] - pr[0]) * us;
         printf("leaf lane per step (us): factor %.2f  writeback+wait %.2f  loads+publish %.2f  solve %.2f  update %.2f  step %.2f; chain total %.1f us\n",
@@ -130,6 +138,12 @@ int main(int argc, char** argv) {
             zerr = std::fmax(zerr, std::fabs(s - A[(size_t)(R - 1) * ld + i]));
         }
         printf("max |L L^T - A| = %.3e, max |L z - r| = %.3e\n", err, zerr);
+        for (int b = 1; b < nmat; ++b) {
+            std::vector<double> Lb((size_t)R * ld); CK(hipMemcpy(Lb.data(), dA + (size_t)b * A.size(), Lb.size() * 8, hipMemcpyDeviceToHost));
+            size_t diff = 0;
+            for (int i = 0; i < R; ++i) for (int j = 0; j <= i && j < n; ++j) diff += Lb[(size_t)i * ld + j] != L[(size_t)i * ld + j];
+            if (diff || b == nmat - 1) printf("object %d vs object 0: %zu differing entries\n", b, diff);
+        }
     }
     return 0;
 }
