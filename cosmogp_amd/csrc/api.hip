@@ -90,6 +90,7 @@ enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_G
 // CGP_* diagnostic switches, read ONCE per handle at cgp_create
 struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
+    double jac_tol = 1.0;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
     long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 0, dag_fill = 70,
@@ -104,6 +105,7 @@ struct CgpEnv {
         bulk_cap = (int)num("CGP_BULK_CAP", 0);
         k4_waves = (int)num("CGP_K4_WAVES", 0);
         jac_inner = (int)num("CGP_JAC_INNER", 1);
+        { const char* v = getenv("CGP_JAC_TOL"); if (v) jac_tol = atof(v); }
         bigtile = num("CGP_BIGTILE", GEMM_BIG_TILE_THRESHOLD);
         gemm_chunk = num("CGP_GEMM_CHUNK", 0);
         no_graph = getenv("CGP_NO_GRAPH") != nullptr;
@@ -1296,7 +1298,9 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     double* K = (double*)h->jK.p;
     double* V = (double*)h->jV.p;
     JacStat* st = (JacStat*)h->jstat.p;
-    hipLaunchKernelGGL(k_jac_norm, dim3(1), dim3(1024), 0, h->stream, (const double*)K, ld, (int)Np, 1.0, st);
+    // (jVD is free until k_jac_finish: its head holds the partial sums of the norm)
+    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)K, ld, (int)Np, (double*)h->jVD.p);
+    hipLaunchKernelGGL(k_jac_norm, dim3(1), dim3(1024), 0, h->stream, (const double*)h->jVD.p, h->env.jac_tol, st);
     hipLaunchKernelGGL(k_jac_identity, dim3(512), dim3(256), 0, h->stream, V, ld, (int)Np);
     HIPCHK(hipGetLastError());
     const int max_sweeps = 40;

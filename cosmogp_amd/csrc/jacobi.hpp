@@ -32,17 +32,29 @@ struct JacStat {
     int pad;
 };
 
-// ||K||_F and the threshold; one workgroup (K is read once, N^2 doubles)
-__global__ __launch_bounds__(1024) void k_jac_norm(const double* __restrict__ K, long ld, int Np, double tol_factor,
-                                                   JacStat* __restrict__ st) {
-    __shared__ double red[16];
+// ||K||_F and the threshold in two launches: per-workgroup partial sums of squares in a fixed order (the result does not
+// depend on the grid's scheduling), then one workgroup adds the partials
+#define JAC_NORM_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_jac_norm_partial(const double* __restrict__ K, long ld, int Np, double* __restrict__ part) {
+    __shared__ double red[4];
     double s = 0.;
-    const long tot = (long)Np * Np;
-    for (long idx = threadIdx.x; idx < tot; idx += 1024) {
-        const long r = idx / Np, c = idx - r * Np;
-        const double v = K[r * ld + c];
-        s += v * v;
+    const long half = Np / 2, tot = (long)Np * half;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long)JAC_NORM_BLOCKS * 256) {
+        const long r = idx / half, c = (idx - r * half) * 2;
+        const double2 v = *(const double2*)(K + r * ld + c);
+        s = fma(v.x, v.x, s);
+        s = fma(v.y, v.y, s);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(1024) void k_jac_norm(const double* __restrict__ part, double tol_factor, JacStat* __restrict__ st) {
+    __shared__ double red[16];
+    double s = part[threadIdx.x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;

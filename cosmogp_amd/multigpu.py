@@ -143,6 +143,9 @@ class Comm(CommBase):
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
         self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
         self.device = device if device is not None else _lib.default_device()
+        # one node by construction: RCCL's bootstrap sockets stay on the loopback interface unless the caller chose one
+        # (a container's other interfaces / host name need not resolve)
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         uid, path = exchange_unique_id(self.rank, self.world, _lib.comm_unique_id)
         self.device.comm_init(self.rank, self.world, uid)
         self.backend = 'rccl'
