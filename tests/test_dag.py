@@ -188,3 +188,37 @@ def test_dag_batch_reports_the_failing_object(monkeypatch):
     assert not good[1].any()
     assert bad[1][2] == 201 and not bad[1][[0, 1, 3]].any()
     assert np.array_equal(bad[0][[0, 1, 3]], good[0][[0, 1, 3]])
+
+
+def test_dag_batch_default_route_at_17_tile_columns(monkeypatch):
+    """The default configuration: three objects of 2100 / 2150 / 2176 points (17 tile columns: the batched entry point takes
+    the single-launch route by itself) with a prediction grid, against the launch-per-step route and the oracle; the sweep of
+    hyper-parameter candidates (cgp_sweep_loglik) over one of them against its candidates evaluated alone."""
+    ns = [2100, 2150, 2176]
+    probs = [_problem(n, 0, 4100 + i) for i, n in enumerate(ns)]
+    xs, ys, es = [p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs]
+    xn = np.random.default_rng(2).uniform(0., 300., 150)
+    dag = _batch({}, monkeypatch, xs, ys, es, xn)
+    steps = _batch({'CGP_NO_DAG_BATCH': '1'}, monkeypatch, xs, ys, es, xn)
+    assert not dag[1].any()
+    np.testing.assert_allclose(dag[0], steps[0], rtol=1e-12)
+    np.testing.assert_allclose(dag[2], steps[2], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(dag[3], steps[3], rtol=0, atol=1e-10)
+    Kc = orc.rbf_kernel_1d(xs[1], [1., 2.], y_err=es[1])
+    mu, var, ll = orc.fit_predict_cho(Kc, ys[1], orc.rbf_kernel_1d(xs[1], [1., 2.], new_x=xn), np.full(len(xn), 1.))
+    assert abs(dag[0][1] - ll) <= 1e-11 * abs(ll)
+    np.testing.assert_allclose(dag[2][1], mu, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dag[3][1], var, rtol=0, atol=1e-9)
+    # sweep: 5 candidates in one call = each candidate in a call of its own, bit for bit
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    dev = _lib.Device(0)
+    dev.set_data(1, xs[2], ys[2])
+    diag = K.diag_term(ns[2], es[2], 0., 0.)
+    kps = np.array([K.kernel_params_1d([a, l]) for a, l in ((1., 2.), (0.7, 3.), (1.3, 1.5), (0.9, 2.5), (1.1, 4.))])
+    ll5, info5 = dev.sweep_loglik(kps, diag)
+    alone = np.array([dev.sweep_loglik(kps[i:i + 1], diag)[0][0] for i in range(5)])
+    dev.close()
+    assert not info5.any() and np.array_equal(ll5, alone)
+    want = orc.log_likelihood_gp(ys[2], xs[2], 'RBF1D', [0.7, 3.], 0., y_err=es[2], svd_method=False)[0]
+    assert abs(ll5[1] - want) <= 1e-11 * abs(want)
