@@ -220,9 +220,10 @@ int cgp_bispev(cgp_handle* h, const double* tx, int64_t nx, const double* ty, in
  * with HIP events on the handle's stream.  stage_ms[12] (may be NULL) receives per-stage
  * averages from a second, event-instrumented pass:
  *   [0] assemble K  [1] potrf_diag  [2] trsm  [3] gemm update  [4] assemble cross
- *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches  [7] gemm flops per fit
+ *   [5] finish (mu/var/loglik)  [6] count of gemm-update launches (of k_chol_dag launches when [11] > 0)  [7] gemm flops per fit
  *   [8] the part of [3] spent in the 128x64-tile form  [9] its launches  [10] its flops
- *   [11] the single-launch factorisation (csrc/dag.hpp; [1]-[3] are then 0)
+ *   [11] the single-launch factorisation (csrc/dag.hpp: one object, or a batch of objects with >= 16 tile columns, 4-16
+ *        objects per launch; [1]-[3] are then 0)
  * stage_ms must hold 12 doubles. */
 int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms);
 
