@@ -850,6 +850,8 @@ void dag_groups(cgp_handle* h, const Prob& P, long& per, long& ngroups) {
     per = dag_batch_route(P) ? std::min<long>(P.B, want) : 1;
     per = std::min<long>(per, std::max(1, dag_grid(h) - 1));            // at least one worker lane
     ngroups = (P.B + per - 1) / per;
+    per = (P.B + ngroups - 1) / ngroups;                                 // even groups: 9 objects = 5 + 4, not 8 + 1
+    ngroups = (P.B + per - 1) / per;
 }
 
 size_t dag_state_words(long per, long nb, long nr) { return ((size_t)per * nr * nb + 3) / 4 * 4; }
