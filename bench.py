@@ -570,15 +570,7 @@ def main():
             t_a = time.perf_counter()
             reps_a = 5
             for _ in range(reps_a):
-                t_r = time.perf_counter()
-                if os.environ.get('CGP_BENCH_DEBUG'):
-                    adev.batch_set_data(1, wl['xs'], wl['ys'], diags)
-                    t_s = time.perf_counter()
-                    adev.batch_fit_resident(wl['kp'], wl['xnew'], None, 0.)
-                    print('api rep: set_data %.3f ms, fit %.3f ms' % ((t_s - t_r) * 1e3, (time.perf_counter() - t_s) * 1e3),
-                          file=sys.stderr)
-                else:
-                    adev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
+                adev.batch_fit(1, wl['xs'], wl['ys'], diags, wl['kp'], wl['xnew'], None, 0.)
             dt_a = (time.perf_counter() - t_a) / reps_a
             extra['api_fits_per_sec'] = round(wl['B'] / dt_a, 2)
             extra['api_note'] = 'cgp_batch_fit with host arrays in (upload of all %d objects) and results out, one handle' % wl['B']

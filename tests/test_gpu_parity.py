@@ -459,6 +459,58 @@ def test_c3_subsample_vs_oracle(cg):
     np.testing.assert_allclose(vard, var, rtol=0, atol=1e-8)
 
 
+@pytest.mark.timeout(600)
+def test_c3_and_c2_full_size_vs_oracle(cg):
+    """BASELINE config[2] (2D N=8192, M=2500) and config[1] (1D N=4096, M=1024) at FULL size against the oracle directly
+    (numpy / LAPACK on the host: ~10 s per object), through both product entry points: cgp_fit (one object, single launch)
+    and cgp_batch_fit (two objects per call: the batched single-launch route, one leaf lane per object)."""
+    from cosmogp_amd import kernel as K
+    dev = cg.default_device()
+    # ---- C3
+    rng = np.random.default_rng(303)
+    n, m = 8192, 2500
+    g = np.linspace(20., 2028., 50)
+    Xn = np.array([[a, b] for a in g for b in g])
+    hyp = [1., 120., 90., 500.]
+    objs = []
+    for _ in range(2):
+        X = rng.uniform(0., 2048., (n, 2))
+        y = np.sin(X[:, 0] / 150.) * np.cos(X[:, 1] / 170.) + 0.1 * rng.standard_normal(n)
+        objs.append((X, y))
+    e = np.full(n, 0.1)
+    kp, diag = K.kernel_params_2d(hyp), K.diag_term(n, e, 0., 0.)
+    bll, binfo, bmu, bvar = dev.batch_fit(2, [o[0] for o in objs], [o[1] for o in objs], [diag, diag], kp, Xn, None, 0.)
+    assert not binfo.any()
+    for i, (X, y) in enumerate(objs):
+        mu, var, ll = orc.fit_predict_cho(orc.rbf_kernel_2d(X, hyp, y_err=e), y, orc.rbf_kernel_2d(X, hyp, new_x=Xn), np.full(m, 1.))
+        assert abs(bll[i] - ll) <= 1e-10 * abs(ll)
+        np.testing.assert_allclose(bmu[i], mu, rtol=0, atol=1e-8 * np.abs(y).max())
+        np.testing.assert_allclose(bvar[i], var, rtol=0, atol=1e-8)
+        if i == 0:
+            dev.set_data(2, X, y)
+            lls, _, mus, vars_ = dev.fit(kp, diag, Xn, None, 0.)
+            assert abs(lls - ll) <= 1e-10 * abs(ll)
+            np.testing.assert_allclose(mus, mu, rtol=0, atol=1e-8 * np.abs(y).max())
+            np.testing.assert_allclose(vars_, var, rtol=0, atol=1e-8)
+    # ---- C2
+    n, m = 4096, 1024
+    xn = np.linspace(0., 600., m)
+    hyp1 = [1., 2.]
+    objs = []
+    for _ in range(2):
+        x = np.sort(rng.uniform(0., 600., n))
+        y = np.sin(0.05 * x) + 0.3 * np.cos(0.31 * x) + 0.1 * rng.standard_normal(n)
+        objs.append((x, y))
+    kp, diag = K.kernel_params_1d(hyp1), K.diag_term(n, e[:n], 0., 0.)
+    bll, binfo, bmu, bvar = dev.batch_fit(1, [o[0] for o in objs], [o[1] for o in objs], [diag, diag], kp, xn, None, 0.)
+    assert not binfo.any()
+    for i, (x, y) in enumerate(objs):
+        mu, var, ll = orc.fit_predict_cho(orc.rbf_kernel_1d(x, hyp1, y_err=e[:n]), y, orc.rbf_kernel_1d(x, hyp1, new_x=xn), np.full(m, 1.))
+        assert abs(bll[i] - ll) <= 1e-10 * abs(ll)
+        np.testing.assert_allclose(bmu[i], mu, rtol=0, atol=1e-8 * np.abs(y).max())
+        np.testing.assert_allclose(bvar[i], var, rtol=0, atol=1e-8)
+
+
 def test_c4_batch_1024_lightcurves(cg):
     """BASELINE config[3]: 1024 x 1D N=512, M=19 in one batched launch sequence; a sample of
     objects is compared with the oracle, all of them are checked for sanity."""
