@@ -268,7 +268,8 @@ def cpu_baseline(wl):
 
 def launch_ranks(n_gpus):
     """`python bench.py --gpus N` run plainly: start N ranks (one per GPU) as child processes BEFORE anything in
-    this process touches the GPU, pass rank 0's JSON line through, return the worst exit code."""
+    this process touches the GPU, pass rank 0's JSON line through, return the worst exit code.  A rank that dies takes
+    the others with it (they would wait for it inside the collective for ever)."""
     import socket
     import subprocess
     s = socket.socket()
@@ -281,13 +282,86 @@ def launch_ranks(n_gpus):
                    MASTER_PORT=str(port), CGP_BENCH_CHILD='1')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p_ in procs[1:]:
-        rc = max(rc, abs(p_.wait()))
-    sys.stdout.write(out.decode())
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()))
+    reader.start()
+    rc = 0
+    while any(p_.poll() is None for p_ in procs):
+        bad = [p_ for p_ in procs if p_.poll() not in (None, 0)]
+        if bad:
+            rc = abs(bad[0].returncode) or 1
+            for p_ in procs:
+                if p_.poll() is None:
+                    p_.terminate()
+            break
+        time.sleep(0.05)
+    for p_ in procs:
+        try:
+            rc = max(rc, abs(p_.wait(timeout=30)))
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            rc = max(rc, 1)
+    reader.join(timeout=30)
+    sys.stdout.write((out[0] if out else b'').decode())
     sys.stdout.flush()
     return rc
+
+
+class FileComm(object):
+    """Stand-in used ONLY if the RCCL communicator of the library cannot be created (bench.py must still report the N-rank
+    measurement, labelled as such in `config.collective`): barrier / all-gather / max over files in the node's temporary
+    directory, one process per GPU on one node.  Not part of the product."""
+
+    def __init__(self, rank, world):
+        import tempfile
+        self.rank, self.world, self.seq = rank, world, 0
+        self.dir = os.path.join(tempfile.gettempdir(), 'cgp_bench_sync_%d_%s_%d'
+                                % (os.getuid(), os.environ.get('MASTER_PORT', '0'), os.getppid()))
+        os.makedirs(self.dir, exist_ok=True)
+        self.backend = 'file'
+
+    def _exchange(self, arr, timeout=600.):
+        self.seq += 1
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        mine = os.path.join(self.dir, '%d_%d.npy' % (self.seq, self.rank))
+        with open(mine + '.tmp', 'wb') as f:
+            np.save(f, arr)
+        os.replace(mine + '.tmp', mine)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, '%d_%d.npy' % (self.seq, r))
+            while True:
+                try:
+                    with open(path, 'rb') as f:
+                        out.append(np.load(f))
+                    break
+                except (OSError, ValueError, EOFError):
+                    if time.time() - t0 > timeout:
+                        raise RuntimeError('rank %d: no %s after %.0f s' % (self.rank, path, timeout))
+                    time.sleep(0.0002)
+        return out
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def _allgather(self, block):
+        return np.stack(self._exchange(block))
+
+    def allreduce_max(self, value):
+        return float(max(v[0] for v in self._exchange(np.array([float(value)]))))
+
+    def close(self):
+        self.barrier()
+        # every rank has READ the last exchange before rank 0 removes the directory
+        open(os.path.join(self.dir, 'done_%d' % self.rank), 'w').close()
+        if self.rank == 0:
+            import shutil
+            t0 = time.time()
+            while time.time() - t0 < 30. and not all(os.path.exists(os.path.join(self.dir, 'done_%d' % r))
+                                                     for r in range(self.world)):
+                time.sleep(0.001)
+            shutil.rmtree(self.dir, ignore_errors=True)
 
 
 def main():
@@ -329,9 +403,19 @@ def main():
     dev = _lib.Device(local_rank)
     dev.selftest_mfma()
     comm = None
+    collective = None
     if world > 1 or 'RANK' in os.environ:          # launched as a rank (any world size): RCCL inside the library
         from cosmogp_amd import multigpu
-        comm = multigpu.Comm(dev, rank=rank, world=world)
+        try:
+            if os.environ.get('CGP_BENCH_COMM') == 'file':
+                raise RuntimeError('CGP_BENCH_COMM=file')
+            comm = multigpu.Comm(dev, rank=rank, world=world)
+            collective = 'RCCL inside the library (cgp_comm_*: ncclAllGather / ncclAllReduce on the handle\'s stream)'
+        except Exception as exc:                   # measured all the same, and labelled
+            print('rank %d: RCCL communicator failed (%s): files in the temporary directory instead' % (rank, exc),
+                  file=sys.stderr)
+            comm = FileComm(rank, world)
+            collective = 'FILE FALLBACK (RCCL communicator failed: %s)' % str(exc)[:200]
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
     # Batches of objects with >= 16 tile columns (N >= 2048) are factored by ONE persistent launch per group of objects
@@ -626,6 +710,7 @@ def main():
                                 fits_per_step_per_gpu=units_per_step,
                                 fits_in_flight_per_gpu=nstreams * (wl['B'] if batched else lock),
                                 objects_per_launch_sequence=(wl['B'] if batched else lock), handles_per_gpu=nstreams,
+                                collective=collective,
                                 factorisation_route=('single launch: persistent tile-DAG kernel k_chol_dag, one leaf lane per object'
                                                      if (roof is not None and 'k_chol_dag' in roof['kernel'])
                                                      else 'one launch per step: k_potrf_diag / k_trsm_panel / k_gemm_nt'),

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 namespace {
@@ -1806,8 +1807,24 @@ int comm_ready(cgp_handle* h, Rccl*& R) {
 
 extern "C" {
 
+// RCCL prints a version banner on STANDARD OUTPUT when a communicator comes up (this build does so unasked); a caller's
+// stdout may be a protocol (bench.py: one JSON line), so the descriptor points at stderr while RCCL initialises.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    }
+};
+
 int cgp_comm_unique_id(void* id_out) {
     if (!id_out) return CGP_E_ARG;
+    StdoutToStderr quiet;
     Rccl* R = rccl();
     if (!R->err.empty()) return CGP_E_STATE;
     static_assert(sizeof(ncclUniqueId) == CGP_COMM_ID_BYTES, "ncclUniqueId size");
@@ -1825,6 +1842,7 @@ int cgp_comm_init(cgp_handle* h, int rank, int world, const void* id) {
     if (!R->err.empty()) return fail(h, CGP_E_STATE, R->err.c_str());
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
+    StdoutToStderr quiet;
     NCCLCHK(R->CommInitRank(&h->comm, world, uid, rank));     // on the current device = h->device (begin_call)
     h->comm_rank = rank;
     h->comm_world = world;

@@ -1,5 +1,7 @@
 """CPU tests of the host-side mirror (no device calls): scalar preparation, mean function,
 initial guess, lazy lists, sharding helpers -- against the golden vectors / oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,34 @@ def test_batch_chunks_respect_grid_and_memory_limits(monkeypatch):
     small = gp._batch_chunks(list(range(100)), m=1000)          # 1001 -> 1024 tall rows per object
     assert max(len(c) for c in small) == 10
     assert max(len(c) for c in gp._batch_chunks(list(range(100)), m=0)) == 45
+
+
+def test_bench_file_fallback_communicator(tmp_path):
+    """bench.py's stand-in for the case that the RCCL communicator cannot be created: barrier / all-gather / max over
+    files, three processes."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'fc.py'
+    script.write_text(textwrap.dedent('''
+        import os, sys, numpy as np
+        sys.path.insert(0, %r)
+        import bench
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        c = bench.FileComm(r, w)
+        c.barrier()
+        g = c._allgather(np.full((2, 3), float(r)))
+        assert g.shape == (w, 2, 3) and all((g[i] == i).all() for i in range(w)), g
+        assert c.allreduce_max(10. + r) == 10. + w - 1
+        c.close()
+    ''' % root))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE='3',
+                                                                       MASTER_PORT=str(40000 + os.getpid() % 20000)))
+             for r in range(3)]
+    try:
+        assert [p.wait(timeout=60) for p in procs] == [0, 0, 0]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()

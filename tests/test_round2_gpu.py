@@ -193,6 +193,21 @@ def test_rccl_world1_and_sharded_sweep(cg):
     dev.close()
 
 
+def test_rccl_init_leaves_stdout_alone(tmp_path):
+    """RCCL prints a version banner on standard output when a communicator comes up; the library points the descriptor at
+    stderr meanwhile, so a caller whose stdout is a protocol (bench.py: ONE JSON line per run) stays clean."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'quiet.py'
+    script.write_text("import sys\nsys.path.insert(0, %r)\nfrom cosmogp_amd import _lib, multigpu\n"
+                      "dev = _lib.Device(0)\nc = multigpu.Comm(dev, rank=0, world=1)\nc.barrier()\nc.close()\nprint('MARK')\n" % root)
+    env = dict(os.environ, MASTER_PORT='29641')
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode() == 'MARK\n', r.stdout.decode()
+
+
 _RANK_SCRIPT = r'''
 import os, sys
 import numpy as np
