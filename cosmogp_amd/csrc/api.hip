@@ -94,8 +94,10 @@ struct CgpEnv {
     double jac_tol = 1.0;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
-    long dag_min_nb = 2, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 8, dag_window = 4, dag_deep_min = 0, dag_fill = 70,
-         dag_lead = 2, dag_dmax = 8, dag_slope = 1;
+    // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
+    // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
+    long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_deep_min = 0, dag_fill = 70,
+         dag_lead = 2, dag_dmax = 0, dag_slope = 1;
     // the same for the batched entry points (several objects per launch: the workers are never short of work, so the list
     // is lazier); at most dag_bmax objects (= leaf lanes) per launch, tile columns >= dag_batch_min_nb
     long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 16, dag_bwindow = 2, dag_bfill = 70, dag_blead = 2, dag_bdmax = 16,
@@ -115,13 +117,13 @@ struct CgpEnv {
         debug = getenv("CGP_DEBUG") != nullptr;
         jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
         no_dag = getenv("CGP_NO_DAG") != nullptr;
-        dag_min_nb = num("CGP_DAG_MIN_NB", 2);
+        dag_min_nb = num("CGP_DAG_MIN_NB", 26);
         dag_timeout_ms = num("CGP_DAG_TIMEOUT_MS", 4000);
         dag_grid = num("CGP_DAG_GRID", 0);
-        dag_depth = num("CGP_DAG_DEPTH", 8);
-        dag_window = num("CGP_DAG_WINDOW", 4);
+        dag_depth = num("CGP_DAG_DEPTH", 0);
+        dag_window = num("CGP_DAG_WINDOW", 0);
         dag_deep_min = 0;
-        dag_dmax = num("CGP_DAG_DMAX", 8);
+        dag_dmax = num("CGP_DAG_DMAX", 0);
         dag_slope = num("CGP_DAG_SLOPE", 1);
         dag_fill = num("CGP_DAG_FILL", 70);
         dag_lead = num("CGP_DAG_LEAD", 2);
@@ -809,8 +811,14 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle:
         sch.depth = std::max(1l, e.dag_bdepth); sch.window = std::max(1l, e.dag_bwindow); sch.fill = 0.01 * e.dag_bfill;
         sch.lead = e.dag_blead; sch.dmax = e.dag_bdmax; sch.slope = e.dag_bslope;
     } else {
-        sch.depth = std::max(1l, e.dag_depth); sch.window = std::max(1l, e.dag_window); sch.fill = 0.01 * e.dag_fill;
-        sch.lead = e.dag_lead; sch.dmax = e.dag_dmax; sch.slope = e.dag_slope;
+        // One object: up to 64 tile columns the chain matters most (panels per far update 8, 4 current columns); larger
+        // factorisations are bulk-bound and gain from deeper, fewer updates (tools/chol_rate.py: N = 16384 53.8 -> 55.4,
+        // N = 32768 58.7 -> 63.3 TFLOP/s)
+        const long auto_depth = nb < 96 ? 8 : (nb < 192 ? 16 : 32), auto_window = nb < 96 ? 4 : 2;
+        sch.depth = e.dag_depth > 0 ? e.dag_depth : auto_depth;
+        sch.window = e.dag_window > 0 ? e.dag_window : auto_window;
+        sch.dmax = e.dag_dmax > 0 ? e.dag_dmax : sch.depth;
+        sch.fill = 0.01 * e.dag_fill; sch.lead = e.dag_lead; sch.slope = e.dag_slope;
     }
     // the schedule's time budget per step is that of a whole GPU whatever the grid and the batch (an object's list must not
     // depend on the number of objects beside it)

@@ -1,5 +1,6 @@
 """Single-launch factorisation (csrc/dag.hpp): one persistent kernel walks the tile DAG of the blocked Cholesky with
-dependency counters in HBM.  It is the default route of a single-object fit; the launch-per-step route
+dependency counters in HBM.  It is the default route of a single-object fit from 26 tile columns on (N > 3200) and of
+batched fits from 16; the launch-per-step route
 (CGP_NO_DAG=1) computes the same tiles with a different association of the sums, so the two agree to rounding
 (tolerances below), each of them is run-to-run bit-reproducible, and both agree with the oracle."""
 import numpy as np
@@ -27,8 +28,11 @@ def _problem(n, m, seed, dim=1):
 def _fit(env, monkeypatch, dim, x, y, e, xn, reps=1):
     from cosmogp_amd import _lib
     from cosmogp_amd import kernel as K
-    for k in ('CGP_NO_DAG', 'CGP_NO_GRAPH', 'CGP_DAG_DEPTH', 'CGP_DAG_GRID', 'CGP_LOOKAHEAD'):
+    for k in ('CGP_NO_DAG', 'CGP_NO_GRAPH', 'CGP_DAG_DEPTH', 'CGP_DAG_GRID', 'CGP_LOOKAHEAD', 'CGP_DAG_MIN_NB'):
         monkeypatch.delenv(k, raising=False)
+    # cgp_fit takes the single launch from 26 tile columns on by default (below, the launch-per-step graph is faster); these
+    # tests run it on every size
+    monkeypatch.setenv('CGP_DAG_MIN_NB', '2')
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     dev = _lib.Device(0)
