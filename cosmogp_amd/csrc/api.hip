@@ -793,7 +793,10 @@ bool dag_batch_route(const Prob& P) { return P.batch_api || P.B > 1; }
 bool dag_eligible(cgp_handle* h, const Prob& P) {
     if (h->env.no_dag || P.tri_base >= 0 || P.wrow0 >= 0 || P.R % NB != 0 || P.Np > 65536 || P.R / NB >= 65536) return false;
     if (dag_batch_route(P)) return !h->env.no_dag_batch && P.Np / NB >= h->env.dag_batch_min_nb;
-    return P.Np / NB >= h->env.dag_min_nb;
+    // one object: worth it once the factorisation has enough steps; prediction rows add work the workers absorb beside the
+    // chain but the launch-per-step route pays for in full, so they count like tile columns (tools/chol_rate.py <sizes> <m>:
+    // the crossover is at 26 / 22 / 13 tile columns for 1 / 4 / 16 tall tile rows)
+    return P.Np / NB >= 2 && P.R / NB > h->env.dag_min_nb;
 }
 
 int dag_grid(cgp_handle* h) { return std::max(2, h->env.dag_grid > 0 ? (int)h->env.dag_grid : h->dag_cus); }
