@@ -100,7 +100,7 @@ struct CgpEnv {
          dag_lead = 2, dag_dmax = 0, dag_slope = 1;
     // the same for the batched entry points (several objects per launch: the workers are never short of work, so the list
     // is lazier); at most dag_bmax objects (= leaf lanes) per launch, tile columns >= dag_batch_min_nb
-    long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 16, dag_bwindow = 2, dag_bfill = 70, dag_blead = 2, dag_bdmax = 16,
+    long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 0, dag_bwindow = 2, dag_bfill = 70, dag_blead = 2, dag_bdmax = 0,
          dag_bslope = 1, dag_border = 1;
     bool no_dag_batch = false;
     void read() {
@@ -130,11 +130,11 @@ struct CgpEnv {
         no_dag_batch = getenv("CGP_NO_DAG_BATCH") != nullptr;
         dag_batch_min_nb = num("CGP_DAG_BATCH_MIN_NB", 16);
         dag_bmax = std::max(0l, std::min(64l, num("CGP_DAG_BMAX", 0)));       // 0: by the tile count (dag_groups)
-        dag_bdepth = num("CGP_DAG_BDEPTH", 16);
+        dag_bdepth = num("CGP_DAG_BDEPTH", 0);
         dag_bwindow = num("CGP_DAG_BWINDOW", 2);
         dag_bfill = num("CGP_DAG_BFILL", 70);
         dag_blead = num("CGP_DAG_BLEAD", 2);
-        dag_bdmax = num("CGP_DAG_BDMAX", 16);
+        dag_bdmax = num("CGP_DAG_BDMAX", 0);
         dag_bslope = num("CGP_DAG_BSLOPE", 1);
         dag_border = num("CGP_DAG_BORDER", 1);
     }
@@ -811,8 +811,14 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle:
     const CgpEnv& e = h->env;
     DagSchedule sch;
     if (batch) {
-        sch.depth = std::max(1l, e.dag_bdepth); sch.window = std::max(1l, e.dag_bwindow); sch.fill = 0.01 * e.dag_bfill;
-        sch.lead = e.dag_blead; sch.dmax = e.dag_bdmax; sch.slope = e.dag_bslope;
+        // panels per far update by the tile count (tools/batch_time.py): short factorisations in small batches are still
+        // chain-bound (N = 4096 x 2: 1.99 ms at depth 8, 2.23 at 16), long ones gain from depth (N = 8192 x 8: 52.7 / 50.7 /
+        // 50.3 ms at 8 / 16 / 32)
+        const long auto_depth = nb < 48 ? 8 : (nb < 96 ? 16 : 32);
+        sch.depth = e.dag_bdepth > 0 ? e.dag_bdepth : auto_depth;
+        sch.dmax = e.dag_bdmax > 0 ? e.dag_bdmax : sch.depth;
+        sch.window = std::max(1l, e.dag_bwindow); sch.fill = 0.01 * e.dag_bfill;
+        sch.lead = e.dag_blead; sch.slope = e.dag_bslope;
     } else {
         // One object: up to 64 tile columns the chain matters most (panels per far update 8, 4 current columns); larger
         // factorisations are bulk-bound and gain from deeper, fewer updates (tools/chol_rate.py: N = 16384 53.8 -> 55.4,
