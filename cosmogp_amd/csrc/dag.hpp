@@ -89,22 +89,25 @@ __device__ __forceinline__ void dag_stamp(const unsigned* ctrl, unsigned v) {
     if (threadIdx.x == 0) dag_st_flag((unsigned*)ctrl + 3, v);
 }
 
-// Every thread of the workgroup calls this.  Wave 0 polls up to three counters (lane l polls word l) until each is
-// >= its expected value; the result travels through an LDS word and the workgroup barrier.  false: aborted.
-__device__ __forceinline__ bool dag_wait_impl(const unsigned* ctrl, long long timeout, int nw, const unsigned* w0, unsigned e0,
-                                         const unsigned* w1, unsigned e1, const unsigned* w2, unsigned e2, int code) {
+// Every thread of the workgroup calls this.  Wave 0 polls up to three counters (lane l polls word l) until each of the first
+// `nw` is >= its expected value; the result travels through an LDS word and the workgroup barrier.  Words nw .. nw + nopt - 1
+// are OPTIONAL: they are read along but never waited for.  Returns 0: aborted, 1: done, 3: done and every optional word had
+// reached its value as well.
+__device__ __forceinline__ int dag_wait_impl(const unsigned* ctrl, long long timeout, int nw, const unsigned* w0, unsigned e0,
+                                        const unsigned* w1, unsigned e1, const unsigned* w2, unsigned e2, int code, int nopt) {
     extern __shared__ __attribute__((aligned(16))) double smem_w[];
     int* okword = (int*)(smem_w + DAG_LDS_DOUBLES);
     const int tid = threadIdx.x;
     if (tid < 64) {
         const unsigned* w = tid == 0 ? w0 : (tid == 1 ? w1 : w2);
         const unsigned e = tid == 0 ? e0 : (tid == 1 ? e1 : e2);
-        const bool active = tid < nw;
+        const bool active = tid < nw + nopt, required = tid < nw;
         int ok = 1;
         long long t0 = 0;
+        unsigned v = e;
         for (unsigned spins = 0;; ++spins) {
-            unsigned v = active ? dag_ld_flag(w) : e;
-            if (__all((int)(v >= e))) break;
+            v = active ? dag_ld_flag(w) : e;
+            if (__all((int)(!required || v >= e))) break;
             if (spins == 0) t0 = wall_clock64();
             __builtin_amdgcn_s_sleep(1);
             if ((spins & 15) == 15) {
@@ -123,10 +126,11 @@ __device__ __forceinline__ bool dag_wait_impl(const unsigned* ctrl, long long ti
                 }
             }
         }
+        if (ok && __all((int)(v >= e))) ok = 3;
         if (tid == 0) *okword = ok;
     }
     __syncthreads();
-    return __builtin_amdgcn_readfirstlane(*okword) != 0;
+    return __builtin_amdgcn_readfirstlane(*okword);
 }
 
 // The control steps of a lane are CALLS (a few hundred cycles per task): the compiler then neither merges the spin loops
@@ -134,7 +138,12 @@ __device__ __forceinline__ bool dag_wait_impl(const unsigned* ctrl, long long ti
 // when they were inlined into the ticket loop, and the result hung on the GPU).
 __device__ __noinline__ int dag_wait(const unsigned* ctrl, long long timeout, int nw, const unsigned* w0, unsigned e0,
                                      const unsigned* w1, unsigned e1, const unsigned* w2, unsigned e2, int code) {
-    return dag_wait_impl(ctrl, timeout, nw, w0, e0, w1, e1, w2, e2, code) ? 1 : 0;
+    return dag_wait_impl(ctrl, timeout, nw, w0, e0, w1, e1, w2, e2, code, 0) ? 1 : 0;
+}
+// the same with one optional word behind the `nw` required ones: 0 aborted, 1 done, 3 done and the optional word was there too
+__device__ __noinline__ int dag_wait_opt(const unsigned* ctrl, long long timeout, const unsigned* w0, unsigned e0,
+                                         const unsigned* w1, unsigned e1, int code) {
+    return dag_wait_impl(ctrl, timeout, 1, w0, e0, w1, e1, nullptr, 0, code, 1);
 }
 
 // publish: every wave drains its write-through stores, the barrier, then ONE lane stores the counter
@@ -478,10 +487,14 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
     // The tile below with panels 0..k-1 applied.  ORDER MATTERS for the no-deadlock argument of the ticket list: the factor is
     // published after THIS wait only (its update precedes every task that needs the factor in the list); the next diagonal
     // tile is waited for after the factor is out, because its last update is listed behind the solves of panel k.
+    int diag_ready = 0;              // the next diagonal tile was already up to date when the tile below was: no second wait
     if (below) {
-        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr, 0, nullptr, 0,
-                                                     0x10000 + k)))
-            return 0;
+        const int r = diag ? __builtin_amdgcn_readfirstlane(dag_wait_opt(ctrl, timeout, p.state + (long)(k + 1) * nb + k, (unsigned)k,
+                                                                         p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, 0x10000 + k))
+                           : __builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + k, (unsigned)k, nullptr,
+                                                                     0, nullptr, 0, 0x10000 + k));
+        if (!r) return 0;
+        diag_ready = r == 3;
     }
     if (prof && tid == 0) prof[0] = wall_clock64();
     // this wave's share of the next diagonal tile: its lower triangle as 20 blocks of 32 rows x 16 columns (block row R =
@@ -513,7 +526,8 @@ __device__ __noinline__ int dag_leaf_step(double* M, long ld, int nb_, int nr_, 
     if (!below) return 2;
     // this wave's share of the next diagonal tile (workers have applied panels 0..k-1): the loads land during the solve
     if (diag) {
-        if (!__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
+        if (!diag_ready &&
+            !__builtin_amdgcn_readfirstlane(dag_wait(ctrl, timeout, 1, p.state + (long)(k + 1) * nb + (k + 1), (unsigned)k, nullptr, 0,
                                                      nullptr, 0, 0x20000 + k)))
             return 0;
 #pragma unroll
