@@ -20,7 +20,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
-    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_sweep_loglik',
+    'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_batch_loo', 'cgp_sweep_loglik',
     'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_allgather', 'cgp_comm_allreduce',
     'cgp_sweep_loglik_sharded', 'cgp_bispev', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
@@ -76,6 +76,7 @@ def load_library():
                                       _i64, ctypes.c_int, _dp, ctypes.c_double, _dp,
                                       ctypes.POINTER(ctypes.c_int32), _dp, _dp]
         lib.cgp_batch_fit_grad.argtypes = [vp, _dp, _dp, ctypes.POINTER(ctypes.c_int32), _dp]
+        lib.cgp_batch_loo.argtypes = [vp, _dp, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int32)]
         lib.cgp_sweep_loglik.argtypes = [vp, _i64, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_int32)]
         lib.cgp_comm_unique_id.argtypes = [ctypes.c_char_p]
         lib.cgp_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
@@ -301,6 +302,7 @@ class Device(object):
                                           _ptr(d))
         self._check(st, 'cgp_batch_set_data')
         self._batch = (dim, B)
+        self._batch_nmax = int(ns.max()) if B else 0
 
     def batch_fit_resident(self, kp, xnew=None, mean_new=None, kss_noise=0., xnew_per_object=False):
         """Fit the resident batch: only kp (7 doubles) and the prediction grid go down.
@@ -343,6 +345,19 @@ class Device(object):
                                           _ptr(sums))
         self._check(st, 'cgp_batch_fit_grad')
         return ll, info, sums
+
+    def batch_loo(self, kp):
+        """Leave-one-out ingredients of every object of the resident batch (cgp_batch_loo): alpha = K^-1 r, beta = K^-1 1,
+        g = diag(K^-1) as (B, Np) arrays (entries beyond an object's n are undefined) and info[B]."""
+        dim, B = self._batch
+        kp = _f64(kp, (7,))
+        npad = -(-max(1, self._batch_nmax) // 128) * 128
+        alpha, beta, g = np.zeros((B, npad)), np.zeros((B, npad)), np.zeros((B, npad))
+        info = np.zeros(B, dtype=np.int32)
+        st = self._lib.cgp_batch_loo(self._h, _ptr(kp), _ptr(alpha), _ptr(beta), _ptr(g),
+                                     info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        self._check(st, 'cgp_batch_loo')
+        return alpha, beta, g, info
 
     def sweep_loglik(self, kps, diag=None):
         """Log-likelihood of the resident object for every row of kps (P, 7) in one launch sequence.

@@ -631,6 +631,48 @@ __global__ void k_put_resid_row(double* __restrict__ M, long ld, long sM, long r
     if (c < ld) M[(long)b * sM + row * ld + c] = (c < ns[b]) ? r[(long)b * sr + c] : 0.;
 }
 
+// row `row` := 1 on the first ns[b] columns, 0 beyond (the all-ones right-hand side of cgp_batch_loo)
+__global__ void k_put_ones_row(double* __restrict__ M, long ld, long sM, long row, const int* __restrict__ ns) {
+    const int b = blockIdx.z;
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ld) M[(long)b * sM + row * ld + c] = (c < ns[b]) ? 1. : 0.;
+}
+
+// Leave-one-out ingredients from W = L^-T (rows wrow0 + t), z = L^-1 r (row zrow) and u = L^-1 1 (row zrow - 1):
+//   alpha_t = W_t . z = (K^-1 r)_t,   beta_t = W_t . u = (K^-1 1)_t,   g_t = |W_t|^2 = (K^-1)_tt
+__global__ __launch_bounds__(256) void k_loo_rows(const double* __restrict__ M, long ld, long sM, int Np, int wrow0, int zrow,
+                                                  const int* __restrict__ ns, double* __restrict__ alpha,
+                                                  double* __restrict__ beta, double* __restrict__ g, long sOut) {
+    const int b = blockIdx.z, t = blockIdx.x;
+    if (t >= ns[b]) return;
+    M += (long)b * sM;
+    const double* w = M + (long)(wrow0 + t) * ld;
+    const double* z = M + (long)zrow * ld;
+    const double* u = M + (long)(zrow - 1) * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red[3][4];
+    double s1 = 0., s2 = 0., s3 = 0.;
+    for (int c = tid * 2; c < Np; c += 512) {
+        const double2 wv = *(const double2*)(w + c), zv = *(const double2*)(z + c), uv = *(const double2*)(u + c);
+        s1 += wv.x * zv.x + wv.y * zv.y;
+        s2 += wv.x * wv.x + wv.y * wv.y;
+        s3 += wv.x * uv.x + wv.y * uv.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        s3 += __shfl_down(s3, off);
+    }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; red[2][wave] = s3; }
+    __syncthreads();
+    if (tid == 0) {
+        alpha[(long)b * sOut + t] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        g[(long)b * sOut + t] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        beta[(long)b * sOut + t] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
 __global__ void k_fill(double* p, long n, double v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
@@ -1278,6 +1320,66 @@ int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t*
     h->last_m = 0;
     h->last_has_mean = false;
     h->last_kss_noise = 0.;
+    return CGP_OK;
+}
+
+// Leave-one-out ingredients of every object of the resident batch in ONE launch sequence (the caller of the path,
+// cosmogp/pull.py:51-90, refits a GP on n - 1 points n times per object: O(n^4); with K = L L^T of ALL n points
+//   k_t' K_-t^-1 v_-t = v_t - (K^-1 v)_t / (K^-1)_tt      and      k_t' K_-t^-1 k_t = K_tt - 1 / (K^-1)_tt
+// give every leave-one-out mean and variance from alpha = K^-1 r, beta = K^-1 1 and g = diag K^-1: O(n^3) once).
+// One sweep over [K; (ones, r); I]: factor K, z = L^-1 r, u = L^-1 1, W = L^-T (triangular-aware), then three dot products per
+// row.  alpha / beta / g: [B][Np] (Np = padded size of the batch), entries t >= n_b untouched.
+int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, double* g, int32_t* info) {
+    CHK(begin_call(h));
+    if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_loo: no resident batch (call cgp_batch_set_data)");
+    if (!kp || !alpha || !beta || !g) return fail(h, CGP_E_ARG, "cgp_batch_loo: bad argument");
+    Prob& Q = h->Q;
+    const long B = Q.B, Np = Q.Np, nblk = Np / NB, tall = Np + NB, ld = Np;
+    Q.R = Np + tall;
+    Q.sM = Q.R * Np;
+    Q.kps = 0;
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
+    CHK(ensure(h, h->qinfo, B * sizeof(int)));
+    CHK(ensure(h, h->qmu, (size_t)B * tall * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * tall * sizeof(double)));
+    CHK(ensure(h, h->bout, (size_t)B * tall * sizeof(double)));
+    CHK(upload_kp(h, kp, 0.));
+    Q.M = (double*)h->qM.p;
+    Q.x = (double*)h->qx.p; Q.sx = Np * Q.dim;
+    Q.r = (double*)h->qr.p; Q.sr = Np;
+    Q.diag = (double*)h->qdiag.p; Q.sd = Np;
+    Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
+    Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
+    Q.info = (int*)h->qinfo.p;
+    Q.ns = (int*)h->qns.p;
+    HIPCHK(hipMemsetAsync(Q.info, 0, sizeof(int) * B, h->stream));
+    CHK(launch_assemble_train(h, Q.dim, Q.B, Q.M, ld, Q.sM, Q.x, Q.sx, Q.diag, Q.sd, Q.ns, Q.Np, true, true, Q.kps));
+    Q.zrow = Np + NB - 1;
+    Q.wrow0 = Q.tri_base = Np + NB;
+    HIPCHK(hipMemset2DAsync(Q.M + Np * ld, (size_t)Q.sM * sizeof(double), 0, (size_t)NB * ld * sizeof(double), B, h->stream));
+    CHK(put_resid_row(h, Q));
+    hipLaunchKernelGGL(k_put_ones_row, dim3((unsigned)((Np + 255) / 256), 1, (unsigned)B), dim3(256), 0, h->stream, Q.M, ld, Q.sM,
+                       Q.zrow - 1, (const int*)Q.ns);
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(256, 1, (unsigned)B), dim3(256), 0, h->stream, Q.M + Q.wrow0 * ld, ld, (int)Np, Q.sM);
+    HIPCHK(hipGetLastError());
+    int st = factor_range(h, Q, 0, Np, 0, Q.R, true);
+    if (st >= 0) {
+        hipLaunchKernelGGL(k_loo_rows, dim3((unsigned)Np, 1, (unsigned)B), dim3(256), 0, h->stream, (const double*)Q.M, ld, Q.sM, (int)Np,
+                           (int)Q.wrow0, (int)Q.zrow, (const int*)Q.ns, (double*)h->qmu.p, (double*)h->bout.p, (double*)h->qvar.p, tall);
+        if (hipGetLastError() != hipSuccess) st = CGP_E_HIP;
+    }
+    Q.wrow0 = Q.zrow = Q.tri_base = -1;
+    if (st < 0) return st;
+    std::vector<int> hinfo(B);
+    CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
+    CHK(d2h_2d(h, alpha, Np * sizeof(double), h->qmu.p, tall * sizeof(double), Np * sizeof(double), B));
+    CHK(d2h_2d(h, beta, Np * sizeof(double), h->bout.p, tall * sizeof(double), Np * sizeof(double), B));
+    CHK(d2h_2d(h, g, Np * sizeof(double), h->qvar.p, tall * sizeof(double), Np * sizeof(double), B));
+    HIPCHK(stream_sync(h));
+    if (info) for (long b = 0; b < B; ++b) info[b] = hinfo[b];
+    h->last_was_batch = false;           // the batch's matrices now hold this layout: cgp_bench_fit must not replay a fit on them
     return CGP_OK;
 }
 

@@ -2,9 +2,12 @@
 of the hot path).
 
 The reference re-builds a GP on N-1 points and predicts, N times per object, one after the
-other (pull.py:51-90: O(N^4)).  Here the leave-one-out problems of ALL objects are batched launch
-sequences on the device (cgp_batch_fit with one prediction point per sub-problem, bucketed by padded
-size), the per-subset mean offsets are the same host O(N) code as the reference.
+other (pull.py:51-90: O(N^4)).  Here ONE factorisation of each object's full matrix gives all its
+leave-one-out predictions (cgp_batch_loo; the identities are in include/cosmogp_hip.h): O(N^3) per object,
+objects bucketed by padded size and batched.  The literal form -- every (object, left-out point) pair as its
+own sub-problem in batched launch sequences (cgp_batch_fit with one prediction point each) -- is kept
+(`LOO_BY_REFITTING = True`, and as the fallback when the full matrix is not positive definite); the two agree
+to rounding (tests/test_gpu_parity.py).  The per-subset mean offsets are the reference's (mean.py:95-97).
 """
 import numpy as np
 from scipy.stats import norm as normal
@@ -17,6 +20,10 @@ from .gaussian_process import gaussian_process, _kparams
 
 gpm = sys.modules['cosmogp_amd.gaussian_process']      # (the package re-exports a class of that name)
 from .mean import return_mean
+
+#: True: leave-one-out by refitting every sub-problem (the reference's own arithmetic, O(N^4)); False: from one
+#: factorisation of the full matrix per object
+LOO_BY_REFITTING = False
 
 
 class build_pull(object):
@@ -66,7 +73,12 @@ class build_pull(object):
             bound = min(float(np.min(o[2] ** 2)) if len(o[0]) else np.inf for o in objs) + float(self.nugget) ** 2
             batched = gpm.SVD_VIA_CHOLESKY_WHEN_PD is True or bound > 1e-14
         results = None
-        if batched:
+        if batched and not LOO_BY_REFITTING:
+            try:
+                results = self._loo_from_full_factor(dev, dim, objs, substract_mean)
+            except np.linalg.LinAlgError:
+                results = None                 # e.g. two coincident points without noise: the sub-problems may still be fine
+        if batched and results is None:
             try:
                 results = self._loo_batched(dev, dim, objs, substract_mean)
             except np.linalg.LinAlgError:
@@ -85,6 +97,58 @@ class build_pull(object):
                 self.pull.append(pull[t])
                 self.residual.append(res[t])
         self.pull_average, self.pull_std = normal.fit(self.pull)
+
+    def _loo_from_full_factor(self, dev, dim, objs, substract_mean):
+        """All leave-one-out predictions of an object from the factor of its FULL matrix (cgp_batch_loo):
+        with r0 = y - mean shape, alpha = K^-1 r0, beta = K^-1 1, g = diag K^-1 and the left-out point t,
+            k_t' K_-t^-1 (r0 - diff_t)_-t = (r0_t - alpha_t / g_t) - diff_t (1 - beta_t / g_t)
+            k_t' K_-t^-1 k_t             = K_tt - 1 / g_t
+        where diff_t = mean of (y - shape) over the kept points (mean.py:95-97) unless `diff` is given.  The cross row of
+        the reference is amp_cross / amp_train times the train row (kernel.py:137-151: the 2D train matrix carries no
+        amplitude), and K(new, new)_tt = amp_train + nugget^2 as in get_prediction.  Returns [(pred, pred_var)] per object."""
+        use_mean = substract_mean or self.y_mean is not None
+        kp = _kparams(dim, self.hyperparameters, self.nugget)
+        rho = kp[1] / kp[0]
+        kss = kp[0] + float(self.nugget) ** 2
+        out = [None] * len(objs)
+        buckets = {}
+        for sn, (y, x, yerr, dd) in enumerate(objs):
+            n = len(y)
+            if n < 2:
+                raise np.linalg.LinAlgError('leave-one-out needs at least two points per object')
+            if use_mean:
+                # shape(x) of the FIXED mean function; the offset of a subset is shape + diff (return_mean with diff = 0)
+                shape = np.atleast_1d(return_mean(y, x, mean_y=self.y_mean, mean_xaxis=self.x_axis_mean, diff=0.) * np.ones(n))
+            else:
+                shape = np.zeros(n)
+            buckets.setdefault((n + 127) // 128 * 128, []).append((sn, shape))
+        for np_ in sorted(buckets, reverse=True):
+            members = buckets[np_]
+            per = max(1, min(gpm.MAX_BATCH_OBJECTS, int(gpm.BATCH_BYTES_LIMIT // ((3 * np_ + 128) * np_ * 8))))
+            for lo in range(0, len(members), per):
+                part = members[lo:lo + per]
+                r0s = [objs[sn][0] - shape for sn, shape in part]
+                dev.batch_set_data(dim, [objs[sn][1] for sn, _ in part], r0s,
+                                   [_kernel.diag_term(len(objs[sn][0]), objs[sn][2], 0., 0.) for sn, _ in part])
+                alpha, beta, g, info = dev.batch_loo(kp)
+                if np.any(info):
+                    b = int(np.nonzero(info)[0][0])
+                    raise np.linalg.LinAlgError('matrix of object %d is not positive definite' % part[b][0])
+                for k, (sn, shape) in enumerate(part):
+                    y, x, yerr, dd = objs[sn]
+                    n = len(y)
+                    a, bt, gg, r0 = alpha[k, :n], beta[k, :n], g[k, :n], r0s[k]
+                    if not use_mean:
+                        diff_t = np.zeros(n)
+                    elif dd is None:
+                        diff_t = (np.sum(r0) - r0) / (n - 1.)
+                    else:
+                        diff_t = np.full(n, float(np.ravel(dd)[0]) if np.ndim(dd) else float(dd))
+                    mu = rho * ((r0 - a / gg) - diff_t * (1. - bt / gg))
+                    ktt = kp[0] + (yerr ** 2 + kp[6])
+                    var = np.abs(kss - rho * rho * (ktt - 1. / gg))
+                    out[sn] = (mu + (shape + diff_t if use_mean else 0.), var)
+        return out
 
     def _loo_batched(self, dev, dim, objs, substract_mean):
         """Every (object, left-out point) pair is one sub-problem; returns [(pred, pred_var)] per object."""

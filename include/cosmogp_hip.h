@@ -205,6 +205,16 @@ int cgp_comm_allreduce(cgp_handle* h, double* buf, int64_t count, int op);
 int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, const double* diag,
                              int64_t chunk, double* loglik, int32_t* info);
 
+/* ---- leave-one-out ingredients (caller of the path) ----------------------------------
+ * cosmogp/pull.py:51-90 builds a GP on n - 1 points and predicts the left-out one, n times per object.  With the factor of
+ * the FULL matrix K (all n points, same kp)
+ *     k_t' K_-t^-1 v_-t = v_t - (K^-1 v)_t / (K^-1)_tt ,     k_t' K_-t^-1 k_t = K_tt - 1 / (K^-1)_tt
+ * so alpha = K^-1 r, beta = K^-1 1 and g = diag(K^-1) give every leave-one-out mean (beta: for a mean offset that depends
+ * on the left-out point, mean.py:95-97) and variance: one factorisation per object instead of n.  Runs on the resident
+ * batch (cgp_batch_set_data); alpha, beta, g: [B][Np] doubles, Np = the batch's padded size (max n rounded up to 128),
+ * entries t >= n_b are not written; info[b] as cgp_batch_fit. */
+int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, double* g, int32_t* info);
+
 /* ---- mean function at the edge of the path ---------------------------------------
  * interpolate_mean_2d, cosmogp/mean.py:36-67, evaluates a bivariate spline with one `bisplev` call per point
  * (:63-65).  cgp_bispev evaluates the tensor-product B-spline (tx[nx], ty[ny], c[(nx-kx-1)*(ny-ky-1)], degrees kx,

@@ -848,12 +848,27 @@ def test_pull_many_objects_default_arguments(cg):
     calls = []
     real = dev.batch_fit
     dev.batch_fit = lambda *a, **k: (calls.append(len(a[1])), real(*a, **k))[1]
+    import sys
+    pm = sys.modules['cosmogp_amd.pull']
+    want_pull, want_res, _ = orc.compute_pull(ys, xs, hyp, nugget=0.03, y_err=es, svd_method=True)
+    # default: every object's leave-one-out predictions from ONE factorisation of its full matrix (cgp_batch_loo)
     bp = cg.build_pull(ys, xs, hyp, nugget=0.03, y_err=es, device=dev)
     bp.compute_pull()                                            # svd_method=True, substract_mean=False
-    assert sorted(calls) == sorted([12 + 35 + 20, 150 + 131])    # two buckets (Np = 128, 256), every sub-problem once
-    want_pull, want_res, _ = orc.compute_pull(ys, xs, hyp, nugget=0.03, y_err=es, svd_method=True)
+    assert calls == []
     np.testing.assert_allclose(bp.pull, want_pull, rtol=0, atol=1e-7)
     np.testing.assert_allclose(bp.residual, want_res, rtol=0, atol=1e-8)
+    # the reference's own arithmetic: every (object, left-out point) pair refitted, as bucketed batches
+    try:
+        pm.LOO_BY_REFITTING = True
+        bl = cg.build_pull(ys, xs, hyp, nugget=0.03, y_err=es, device=dev)
+        bl.compute_pull()
+    finally:
+        pm.LOO_BY_REFITTING = False
+    assert sorted(calls) == sorted([12 + 35 + 20, 150 + 131])    # two buckets (Np = 128, 256), every sub-problem once
+    np.testing.assert_allclose(bl.pull, want_pull, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(bl.residual, want_res, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(bp.pull, bl.pull, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(bp.residual, bl.residual, rtol=0, atol=1e-10)
     bm = cg.build_pull(ys[:2], xs[:2], hyp, nugget=0.03, y_err=es[:2], device=dev)
     bm.compute_pull(substract_mean=True)
     want_pull, _, _ = orc.compute_pull(ys[:2], xs[:2], hyp, nugget=0.03, y_err=es[:2], svd_method=True, substract_mean=True)
@@ -862,6 +877,78 @@ def test_pull_many_objects_default_arguments(cg):
     b0 = cg.build_pull([np.sin(x0)], [x0], [1., 1.], device=dev)          # no y_err, no nugget: singular sub-matrices
     b0.compute_pull()
     assert len(b0.pull) == 12 and np.all(np.isfinite(b0.residual))
+
+
+def test_pull_from_full_factor_equals_refitting(cg):
+    """Leave-one-out predictions from one factorisation per object (cgp_batch_loo, the default of build_pull) against the
+    literal refits, for everything that enters the identities: 1D and 2D kernels (the 2D train matrix carries no amplitude,
+    cross rows do; lxy != 0), a nugget, a mean function with the per-subset offset of mean.py:95-97, a given `diff`,
+    substract_mean, objects of several padded sizes in one call."""
+    import sys
+    pm = sys.modules['cosmogp_amd.pull']
+    rng = np.random.default_rng(77)
+
+    def both(make):
+        outs = []
+        for literal in (False, True):
+            try:
+                pm.LOO_BY_REFITTING = literal
+                bp = make()
+            finally:
+                pm.LOO_BY_REFITTING = False
+            outs.append((np.array(bp.pull), np.array(bp.residual)))
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-9)
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-10)
+        return outs[0]
+
+    sizes = [9, 140, 60]
+    xs = [np.sort(rng.uniform(0., 0.6 * n + 4., n)) for n in sizes]
+    es = [rng.uniform(0.05, 0.2, n) for n in sizes]
+    ys = [1.5 + np.sin(x / 3.) + e * rng.standard_normal(len(x)) for x, e in zip(xs, es)]
+    gx = np.linspace(-5., 100., 60)
+    gm = 1.5 + 0.8 * np.sin(gx / 3.)
+
+    def run(**kw):
+        args = dict(kw)
+        cp = {k: args.pop(k) for k in ('diff', 'substract_mean', 'svd_method') if k in args}
+        def make():
+            bp = cg.build_pull(ys, xs, [0.9, 2.5], y_err=es, **args)
+            bp.compute_pull(**cp)
+            return bp
+        return both(make)
+
+    run(nugget=0.05)
+    run(nugget=0.05, substract_mean=True)
+    run(nugget=0.0, y_mean=gm, x_axis_mean=gx)
+    run(nugget=0.02, y_mean=gm, x_axis_mean=gx, diff=[0.3, -0.1, 0.2], svd_method=False)
+    # 2D
+    sizes2 = [30, 130]
+    X = [rng.uniform(0., 40., (n, 2)) for n in sizes2]
+    E = [rng.uniform(0.05, 0.15, n) for n in sizes2]
+    Y = [np.sin(x[:, 0] / 6.) * np.cos(x[:, 1] / 7.) + e * rng.standard_normal(len(x)) for x, e in zip(X, E)]
+
+    def make2():
+        bp = cg.build_pull(Y, X, [0.8, 6.0, 7.5, 9.0], nugget=0.03, y_err=E, kernel='RBF2D')
+        bp.compute_pull()
+        return bp
+    pull2, res2 = both(make2)
+    want_pull, want_res, _ = orc.compute_pull(Y, X, [0.8, 6.0, 7.5, 9.0], nugget=0.03, y_err=E, kernel='RBF2D', svd_method=True)
+    np.testing.assert_allclose(pull2, want_pull, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(res2, want_res, rtol=0, atol=1e-8)
+    # one object of 3000 points: 3000 refits of 2999 points are out of reach, one factorisation takes milliseconds
+    n = 3000
+    x = np.sort(rng.uniform(0., 0.4 * n, n))
+    e = np.full(n, 0.1)
+    y = np.sin(x / 3.) + e * rng.standard_normal(n)
+    bp = cg.build_pull([y], [x], [1.0, 2.0], nugget=0.0, y_err=[e])
+    bp.compute_pull()
+    assert len(bp.pull) == n and abs(bp.pull_std - 1.) < 0.1 and abs(bp.pull_average) < 0.1
+    t = 1234                                            # one of them against the oracle's refit
+    keep = np.ones(n, dtype=bool); keep[t] = False
+    Kc = orc.rbf_kernel_1d(x[keep], [1., 2.], y_err=e[keep])
+    mu, var, _ = orc.fit_predict_cho(Kc, y[keep], orc.rbf_kernel_1d(x[keep], [1., 2.], new_x=x[t:t + 1]), np.full(1, 1.))
+    assert abs(bp.residual[t] - (mu[0] - y[t])) < 1e-9
+    assert abs(bp.pull[t] - (mu[0] - y[t]) / np.sqrt(e[t] ** 2 + abs(var[0]))) < 1e-8
 
 
 def test_abi_status_codes(cg):
