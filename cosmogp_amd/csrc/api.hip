@@ -157,7 +157,7 @@ struct cgp_handle {
     struct PinOut { void* dst; const void* src; size_t bytes; size_t dpitch, spitch, width, rows; };
     std::vector<PinOut> pin_out;
     // single-launch factorisation (dag.hpp): task lists by (tile shape, objects per launch, schedule), counters, number of CUs
-    struct DagList { DevBuf tasks; long nb = -1, nr = -1, nmat = -1, sig = -1; int ntasks = 0; unsigned long used = 0; };
+    struct DagList { DevBuf tasks, state0; long nb = -1, nr = -1, nmat = -1, sig = -1; int ntasks = 0; bool tri = false; unsigned long used = 0; };
     std::vector<DagList> dag_lists;
     unsigned long dag_clock = 0;
     DevBuf dstate;
@@ -715,7 +715,7 @@ int cgp_destroy(cgp_handle* h) {
     (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
     (void)stream_sync(h);
-    for (auto& l : h->dag_lists) free_buf(l.tasks);
+    for (auto& l : h->dag_lists) { free_buf(l.tasks); free_buf(l.state0); }
     DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
@@ -832,9 +832,17 @@ int put_resid_row(cgp_handle* h, Prob& P) {
 // likes and get the same bits.
 bool dag_batch_route(const Prob& P) { return P.batch_api || P.B > 1; }
 
+// gradient / leave-one-out layout: [K; one dense block (residual in its last row); Np identity rows] (device_grad, cgp_batch_loo)
+bool dag_tri_layout(const Prob& P) {
+    return P.tri_base >= 0 && P.tri_base == P.Np + NB && P.wrow0 == P.tri_base && P.zrow == P.Np + NB - 1 && P.R == 2 * P.Np + NB;
+}
+
 bool dag_eligible(cgp_handle* h, const Prob& P) {
-    if (h->env.no_dag || P.tri_base >= 0 || P.wrow0 >= 0 || P.R % NB != 0 || P.Np > 65536 || P.R / NB >= 65536) return false;
+    const bool tri = dag_tri_layout(P);
+    if (h->env.no_dag || (!tri && (P.tri_base >= 0 || P.wrow0 >= 0)) || P.R % NB != 0 || P.Np > 65536 || P.R / NB >= 32768) return false;
     if (dag_batch_route(P)) return !h->env.no_dag_batch && P.Np / NB >= h->env.dag_batch_min_nb;
+    // (identity row tiles carry about half the work of dense ones)
+    if (tri) return P.Np / NB >= 2 && P.Np / NB + 1 + P.Np / NB / 2 > h->env.dag_min_nb;
     // one object: worth it once the factorisation has enough steps; prediction rows add work the workers absorb beside the
     // chain but the launch-per-step route pays for in full, so they count like tile columns (tools/chol_rate.py <sizes> <m>:
     // the crossover is at 26 / 22 / 13 tile columns for 1 / 4 / 16 tall tile rows)
@@ -849,7 +857,7 @@ void drop_graphs(cgp_handle* h) {
 }
 
 // the list for `nmat` objects of nb x nr tiles (built and uploaded on first use; a few shapes stay cached)
-int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle::DagList** out, bool build) {
+int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, bool tri, cgp_handle::DagList** out, bool build) {
     const CgpEnv& e = h->env;
     DagSchedule sch;
     if (batch) {
@@ -874,10 +882,11 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle:
     // the schedule's time budget per step is that of a whole GPU whatever the grid and the batch (an object's list must not
     // depend on the number of objects beside it)
     sch.workers = h->dag_cus - 1;
+    sch.tri_row0 = tri ? nb + 1 : -1;
     const int order = batch ? (int)e.dag_border : 0;
     const long sig = ((((((sch.depth * 100 + sch.window) * 100 + sch.dmax) * 100 + sch.slope) * 1000 + (long)(sch.fill * 100)) * 10 + sch.lead) * 2 + order) * 2 + (batch ? 1 : 0);
     for (auto& l : h->dag_lists)
-        if (l.nb == nb && l.nr == nr && l.nmat == nmat && l.sig == sig) { l.used = ++h->dag_clock; *out = &l; return 0; }
+        if (l.nb == nb && l.nr == nr && l.nmat == nmat && l.sig == sig && l.tri == tri) { l.used = ++h->dag_clock; *out = &l; return 0; }
     if (!build) return fail(h, CGP_E_STATE, "single-launch factorisation: task list missing");
     if (h->dag_lists.size() >= 6) {
         // evict the least recently used list; captured graphs may point to it
@@ -886,6 +895,7 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle:
         HIPCHK(stream_sync(h));
         drop_graphs(h);
         free_buf(h->dag_lists[v].tasks);
+        free_buf(h->dag_lists[v].state0);
         h->dag_lists.erase(h->dag_lists.begin() + v);
     }
     std::vector<int4> t;
@@ -895,7 +905,14 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, cgp_handle:
     CHK(ensure(h, l.tasks, t.size() * sizeof(int4)));
     HIPCHK(hipMemcpyAsync(l.tasks.p, t.data(), t.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(stream_sync(h));
-    l.nb = nb; l.nr = nr; l.nmat = nmat; l.sig = sig; l.ntasks = (int)t.size(); l.used = ++h->dag_clock;
+    if (tri) {
+        std::vector<unsigned> st0;
+        dag_initial_state(nb, nr, sch, st0);
+        CHK(ensure(h, l.state0, st0.size() * sizeof(unsigned)));
+        HIPCHK(hipMemcpyAsync(l.state0.p, st0.data(), st0.size() * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(stream_sync(h));
+    }
+    l.nb = nb; l.nr = nr; l.nmat = nmat; l.sig = sig; l.tri = tri; l.ntasks = (int)t.size(); l.used = ++h->dag_clock;
     if (e.debug) fprintf(stderr, "cgp: dag task list nb=%ld nr=%ld objects=%ld (%s): %d tasks\n", nb, nr, nmat, batch ? "batch" : "single", l.ntasks);
     *out = &l;
     return 0;
@@ -927,8 +944,8 @@ int dag_build(cgp_handle* h, const Prob& P) {
     long per, ngroups;
     dag_groups(h, P, per, ngroups);
     cgp_handle::DagList* l;
-    CHK(dag_list(h, nb, nr, per, dag_batch_route(P), &l, true));
-    if (P.B % per) CHK(dag_list(h, nb, nr, P.B % per, dag_batch_route(P), &l, true));
+    CHK(dag_list(h, nb, nr, per, dag_batch_route(P), dag_tri_layout(P), &l, true));
+    if (P.B % per) CHK(dag_list(h, nb, nr, P.B % per, dag_batch_route(P), dag_tri_layout(P), &l, true));
     const size_t words = (size_t)ngroups * (8 + dag_state_words(per, nb, nr));
     if (h->dstate.cap < words * sizeof(unsigned)) {
         HIPCHK(stream_sync(h));
@@ -956,7 +973,11 @@ int launch_dag(cgp_handle* h, Prob& P) {
     for (long g = 0; g < ngroups; ++g) {
         const long b0 = g * per, nmat = std::min(per, P.B - b0);
         cgp_handle::DagList* l;
-        CHK(dag_list(h, nb, nr, nmat, dag_batch_route(P), &l, false));
+        CHK(dag_list(h, nb, nr, nmat, dag_batch_route(P), dag_tri_layout(P), &l, false));
+        if (l->tri)         // the identity row tiles start with their zero panels counted
+            for (long o = 0; o < nmat; ++o)
+                HIPCHK(hipMemcpyAsync((unsigned*)h->dstate.p + 8 * ngroups + g * sw + o * nr * nb, l->state0.p,
+                                      (size_t)nr * nb * sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
         DagParams dp;
         dp.M = P.M + b0 * P.sM; dp.ld = P.Np; dp.nb = (int)nb; dp.nr = (int)nr;
         dp.nmat = (int)nmat; dp.sM = P.sM; dp.sW = P.sW; dp.sLd = P.sLd;
@@ -1100,7 +1121,12 @@ int device_grad(cgp_handle* h, Prob& P) {
     hipLaunchKernelGGL(k_set_identity_rows, dim3(256, 1, (unsigned)B), dim3(256), 0, h->stream, P.M + P.wrow0 * ld, ld,
                        (int)P.Np, P.sM);
     HIPCHK(hipGetLastError());
-    CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    if (dag_eligible(h, P)) {
+        CHK(dag_build(h, P));
+        CHK(launch_dag(h, P));
+    } else {
+        CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    }
     CHK(launch_finish(h, P, P.Np, true, false));            // mu := alpha = W z; scal := loglik, logdet
     CHK(ensure(h, h->bC, (size_t)B * P.Np * P.Np * sizeof(double)));
     CHK(launch_gemm(h, (int)B, (double*)h->bC.p, P.Np, P.Np * P.Np, P.M + P.wrow0 * ld, P.M + P.wrow0 * ld, ld, P.sM,
@@ -1262,6 +1288,7 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     CHK(d2h(h, &info, P.info, sizeof(int)));
     CHK(d2h(h, sums, h->bgrad.p, 5 * sizeof(double)));
     HIPCHK(stream_sync(h));
+    CHK(dag_check(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
@@ -1311,6 +1338,7 @@ int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t*
     CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
     CHK(d2h(h, gs.data(), h->bgrad.p, gs.size() * sizeof(double)));
     HIPCHK(stream_sync(h));
+    CHK(dag_check(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1364,7 +1392,13 @@ int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, 
                        Q.zrow - 1, (const int*)Q.ns);
     hipLaunchKernelGGL(k_set_identity_rows, dim3(256, 1, (unsigned)B), dim3(256), 0, h->stream, Q.M + Q.wrow0 * ld, ld, (int)Np, Q.sM);
     HIPCHK(hipGetLastError());
-    int st = factor_range(h, Q, 0, Np, 0, Q.R, true);
+    int st = 0;
+    if (dag_eligible(h, Q)) {
+        st = dag_build(h, Q);
+        if (st >= 0) st = launch_dag(h, Q);
+    } else {
+        st = factor_range(h, Q, 0, Np, 0, Q.R, true);
+    }
     if (st >= 0) {
         hipLaunchKernelGGL(k_loo_rows, dim3((unsigned)Np, 1, (unsigned)B), dim3(256), 0, h->stream, (const double*)Q.M, ld, Q.sM, (int)Np,
                            (int)Q.wrow0, (int)Q.zrow, (const int*)Q.ns, (double*)h->qmu.p, (double*)h->bout.p, (double*)h->qvar.p, tall);
@@ -1378,6 +1412,7 @@ int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, 
     CHK(d2h_2d(h, beta, Np * sizeof(double), h->bout.p, tall * sizeof(double), Np * sizeof(double), B));
     CHK(d2h_2d(h, g, Np * sizeof(double), h->qvar.p, tall * sizeof(double), Np * sizeof(double), B));
     HIPCHK(stream_sync(h));
+    CHK(dag_check(h));
     if (info) for (long b = 0; b < B; ++b) info[b] = hinfo[b];
     h->last_was_batch = false;           // the batch's matrices now hold this layout: cgp_bench_fit must not replay a fit on them
     return CGP_OK;

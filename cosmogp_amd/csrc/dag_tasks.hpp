@@ -34,6 +34,11 @@ struct DagSchedule {
     long depth = 8, window = 4, lead = 2, dmax = 8, slope = 1, workers = 255;
     long deep_min = 0;      // (kept for the probe's command line; unused)
     double step_us = 58., task_us = 10., panel_us = 17., trsm_us = 16., fill = 0.7;
+    // tri_row0 >= 0: the row tiles from tri_row0 on hold IDENTITY rows (cgp_fit_grad, cgp_batch_loo: they become W = L^-T,
+    // upper triangular): row tile tri_row0 + t is zero left of column tile t, so its tiles (., j < t) do not exist and the
+    // others start with t panels "applied" (they are zero contributions)
+    long tri_row0 = -1;
+    long first(long i) const { return tri_row0 >= 0 && i >= tri_row0 ? i - tri_row0 : 0; }
 };
 
 // `steps` (optional) receives the segment boundaries of the list: [0] = 0, [1] = end of the solves of panel 0, then three per
@@ -42,6 +47,8 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
     const long window = std::max<long>(1, sc.window), depth = std::max<long>(1, sc.depth), dmax = std::max(depth, sc.dmax);
     t.clear();
     std::vector<long> applied((size_t)nr * nb, 0);         // panels already scheduled onto tile (i, j)
+    for (long i = 0; i < nr; ++i)
+        for (long j = 0; j < nb; ++j) applied[(size_t)i * nb + j] = j < sc.first(i) ? nb + 1 : sc.first(i);   // nb + 1: no such tile
     double spent = 0.;                                     // worker time of this step's tasks (us)
     // one task for tile (i, j): panels [applied, min(k + 1, applied + cap)); returns false if there was nothing to do
     auto tile = [&](long k, long i, long j, long cap) {
@@ -56,7 +63,8 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
     };
     auto column = [&](long k, long j, long cap) { for (long i = j; i < nr; ++i) tile(k, i, j, cap); };
     if (steps) steps->assign(1, 0);
-    for (long i = 2; i < nr; ++i) t.push_back(make_int4((int)i, 0, 0, 0));
+    for (long i = 2; i < nr; ++i)
+        if (sc.first(i) == 0) t.push_back(make_int4((int)i, 0, 0, 0));
     if (steps) steps->push_back(t.size());
     for (long k = 0; k < nb; ++k) {
         if (k > 0 && steps) steps->push_back(t.size());
@@ -64,7 +72,8 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
         if (k + 1 < nb) column(k, k + 1, nb);
         if (steps) steps->push_back(t.size());
         if (k + 1 < nb)
-            for (long i = k + 3; i < nr; ++i) { t.push_back(make_int4((int)i, (int)(k + 1), 0, 0)); spent += sc.trsm_us; }
+            for (long i = k + 3; i < nr; ++i)
+                if (sc.first(i) <= k + 1) { t.push_back(make_int4((int)i, (int)(k + 1), 0, 0)); spent += sc.trsm_us; }
         if (steps) steps->push_back(t.size());
         for (long j = k + 2; j < nb && j <= k + window; ++j) column(k, j, nb);
         if (depth == 1) {
@@ -83,6 +92,13 @@ inline void dag_build_tasks(long nb, long nr, const DagSchedule& sc, std::vector
                 if (k + 1 - applied[(size_t)i * nb + j] >= depth) tile(k, i, j, dmax);
     }
     if (steps) steps->push_back(t.size());
+}
+
+// counters of one object before the launch: 0, except the identity row tiles (DagSchedule::tri_row0)
+inline void dag_initial_state(long nb, long nr, const DagSchedule& sc, std::vector<unsigned>& st) {
+    st.assign((size_t)nr * nb, 0u);
+    for (long i = 0; i < nr; ++i)
+        for (long j = sc.first(i); j < nb; ++j) st[(size_t)i * nb + j] = (unsigned)sc.first(i);
 }
 
 // The list for `nmat` same-shape objects: the single-object list of every object (object index in the upper half of .x),

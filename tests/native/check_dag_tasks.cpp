@@ -5,13 +5,14 @@
 int main(int argc, char** argv) {
     int bad = 0;
     for (long nb : {2, 3, 8, 17, 32, 64, 128})
-        for (long tall : {0, 1, 20})
+        for (long tall : {0, 1, 20, -1})      // -1: the gradient / leave-one-out layout: one dense tall tile row + nb identity row tiles
             for (long depth : {1, 2, 4, 8, 16})
                 for (long window : {1, 2, 4, 8})
                     for (long dm : {0, 12, 36})
                         for (double fill : {0.3, 1.0, 2.0}) {
                             DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4; sc.dmax = depth + (window % 3) * 4; sc.slope = 1 + dm / 20;
-                            const long nr = nb + tall;
+                            const long nr = tall >= 0 ? nb + tall : 2 * nb + 1;
+                            if (tall < 0) sc.tri_row0 = nb + 1;
                             // several objects side by side (every object is checked with its own counters and leaf lane),
                             // both interleaving orders
                             for (int variant = 0; variant < (nb <= 32 ? 3 : 1); ++variant) {
@@ -22,7 +23,9 @@ int main(int argc, char** argv) {
                             for (long ob = 0; ob < nmat; ++ob) {
                             std::vector<int4> t;
                             for (const int4& d : tall_list) if ((d.x >> 16) == ob) { int4 e = d; e.x &= 0xffff; t.push_back(e); }
-                            std::vector<int> state(nr * nb, 0);       // simulated in list order with the leaf lane as far ahead as it can be
+                            std::vector<unsigned> st0;
+                            dag_initial_state(nb, nr, sc, st0);
+                            std::vector<int> state(st0.begin(), st0.end());       // simulated in list order with the leaf lane as far ahead as it can be
                             int leaf_k = 0;                            // leaf has finished potrf(leaf_k - 1) and near trsm
                             // the leaf lane exactly as dag_leaf_step orders its waits and publishes (sub = how far step leaf_k got)
                             int sub = 0;
@@ -64,7 +67,7 @@ int main(int argc, char** argv) {
                                 if (!ok) printf("FORWARD DEP nb=%ld tall=%ld d=%ld w=%ld dm=%ld fill=%.1f at task %zu (%d,%d,%d,%d type %d)\n", nb, tall, depth, window, dm, fill, q, i, j, k0, k1, type);
                             }
                             leaf_advance();
-                            if (ok) for (long i = 0; i < nr; ++i) for (long j = 0; j < nb && j <= i; ++j) if (state[i * nb + j] != j + 1) { ok = false; printf("INCOMPLETE nb=%ld tall=%ld d=%ld w=%ld dm=%ld tile (%ld,%ld) state %d\n", nb, tall, depth, window, dm, i, j, state[i * nb + j]); break; }
+                            if (ok) for (long i = 0; i < nr; ++i) for (long j = 0; j < nb && j <= i; ++j) if (j >= sc.first(i) && state[i * nb + j] != j + 1) { ok = false; printf("INCOMPLETE nb=%ld tall=%ld d=%ld w=%ld dm=%ld tile (%ld,%ld) state %d\n", nb, tall, depth, window, dm, i, j, state[i * nb + j]); break; }
                             bad += !ok;
                             }
                             }

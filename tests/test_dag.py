@@ -226,3 +226,64 @@ def test_dag_batch_default_route_at_17_tile_columns(monkeypatch):
     assert not info5.any() and np.array_equal(ll5, alone)
     want = orc.log_likelihood_gp(ys[2], xs[2], 'RBF1D', [0.7, 3.], 0., y_err=es[2], svd_method=False)[0]
     assert abs(ll5[1] - want) <= 1e-11 * abs(want)
+
+
+# ---- gradient / leave-one-out layout ([K; residual block; identity rows -> W = L^-T]) on the single-launch route ----------------
+
+def _grad_and_loo(env, monkeypatch, xs, ys, es):
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    for k in ('CGP_NO_DAG', 'CGP_NO_DAG_BATCH', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_MIN_NB', 'CGP_DAG_GRID', 'CGP_DAG_BMAX'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = _lib.Device(0)
+    kp = K.kernel_params_1d([1., 2.], 0.03)
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    dev.set_data(1, xs[0], ys[0])
+    single = dev.fit_grad(kp, diags[0])
+    dev.batch_set_data(1, xs, ys, diags)
+    bgrad = dev.batch_fit_grad_resident(kp)
+    loo = dev.batch_loo(kp)
+    dev.close()
+    return single, bgrad, loo
+
+
+def test_dag_gradient_and_loo_layout(monkeypatch):
+    """cgp_fit_grad, cgp_batch_fit_grad and cgp_batch_loo factor [K; residual block; identity rows] in one sweep; the identity
+    row tiles are triangular (row tile t is zero left of column tile t), which the task list honours (no tasks for the zero
+    tiles, counters start at t).  Single-launch route (forced for these 3-5 tile-column objects, with 5 workgroups too)
+    against the launch-per-step route and the oracle's gradient."""
+    ns = [600, 385, 640]
+    probs = [_problem(n, 0, 5200 + i) for i, n in enumerate(ns)]
+    xs, ys, es = [p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs]
+    force = {'CGP_DAG_MIN_NB': '2', 'CGP_DAG_BATCH_MIN_NB': '2'}
+    ref = _grad_and_loo({'CGP_NO_DAG': '1'}, monkeypatch, xs, ys, es)
+    for env in (force, dict(force, CGP_DAG_GRID='5', CGP_DAG_BMAX='2')):
+        got = _grad_and_loo(env, monkeypatch, xs, ys, es)
+        assert abs(got[0][0] - ref[0][0]) <= 1e-12 * abs(ref[0][0])
+        np.testing.assert_allclose(got[0][2], ref[0][2], rtol=1e-9, atol=1e-9)
+        assert not got[1][1].any()
+        np.testing.assert_allclose(got[1][0], ref[1][0], rtol=1e-12)
+        np.testing.assert_allclose(got[1][2], ref[1][2], rtol=1e-9, atol=1e-9)
+        assert not got[2][3].any()
+        for i, n in enumerate(ns):
+            for q in range(3):
+                np.testing.assert_allclose(got[2][q][i, :n], ref[2][q][i, :n], rtol=1e-9, atol=1e-10)
+    # the oracle's gradient for the single object (moment sums -> chain rule on the host)
+    from cosmogp_amd import kernel as K
+    grad = K.gradient_from_sums_1d([1., 2.], 0.03, ref[0][2])
+    want = orc.log_likelihood_gradient(ys[0], xs[0], 'RBF1D', [1., 2.], 0.03, y_err=es[0])
+    np.testing.assert_allclose(grad, want, rtol=1e-7, atol=1e-7)
+
+
+def test_dag_gradient_default_route_at_4096(monkeypatch):
+    """Default thresholds: a 4096-point object's gradient and leave-one-out sweep take the single launch by themselves."""
+    x, y, e, _ = _problem(4096, 0, 77)
+    got = _grad_and_loo({}, monkeypatch, [x], [y], [e])
+    ref = _grad_and_loo({'CGP_NO_DAG': '1'}, monkeypatch, [x], [y], [e])
+    assert abs(got[0][0] - ref[0][0]) <= 1e-12 * abs(ref[0][0])
+    np.testing.assert_allclose(got[0][2], ref[0][2], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(got[1][2], ref[1][2], rtol=1e-8, atol=1e-8)
+    for q in range(3):
+        np.testing.assert_allclose(got[2][q][0], ref[2][q][0], rtol=1e-8, atol=1e-9)
