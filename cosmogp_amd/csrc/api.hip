@@ -96,7 +96,7 @@ struct CgpEnv {
     bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
-    long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_deep_min = 0, dag_fill = 70,
+    long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
          dag_lead = 2, dag_dmax = 0, dag_slope = 1;
     // the same for the batched entry points (several objects per launch: the workers are never short of work, so the list
     // is lazier); at most dag_bmax objects (= leaf lanes) per launch, tile columns >= dag_batch_min_nb
@@ -122,7 +122,6 @@ struct CgpEnv {
         dag_grid = num("CGP_DAG_GRID", 0);
         dag_depth = num("CGP_DAG_DEPTH", 0);
         dag_window = num("CGP_DAG_WINDOW", 0);
-        dag_deep_min = 0;
         dag_dmax = num("CGP_DAG_DMAX", 0);
         dag_slope = num("CGP_DAG_SLOPE", 1);
         dag_fill = num("CGP_DAG_FILL", 70);

@@ -32,7 +32,6 @@
 
 struct DagSchedule {
     long depth = 8, window = 4, lead = 2, dmax = 8, slope = 1, workers = 255;
-    long deep_min = 0;      // (kept for the probe's command line; unused)
     double step_us = 58., task_us = 10., panel_us = 17., trsm_us = 16., fill = 0.7;
     // tri_row0 >= 0: the row tiles from tri_row0 on hold IDENTITY rows (cgp_fit_grad, cgp_batch_loo: they become W = L^-T,
     // upper triangular): row tile tri_row0 + t is zero left of column tile t, so its tiles (., j < t) do not exist and the

@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
                 for (long window : {1, 2, 4, 8})
                     for (long dm : {0, 12, 36})
                         for (double fill : {0.3, 1.0, 2.0}) {
-                            DagSchedule sc; sc.depth = depth; sc.window = window; sc.deep_min = dm; sc.fill = fill; sc.lead = 1 + (depth + window) % 4; sc.dmax = depth + (window % 3) * 4; sc.slope = 1 + dm / 20;
+                            DagSchedule sc; sc.depth = depth; sc.window = window; sc.fill = fill; sc.lead = 1 + (depth + window) % 4; sc.dmax = depth + (window % 3) * 4; sc.slope = 1 + dm / 20;
                             const long nr = tall >= 0 ? nb + tall : 2 * nb + 1;
                             if (tall < 0) sc.tri_row0 = nb + 1;
                             // several objects side by side (every object is checked with its own counters and leaf lane),
