@@ -404,8 +404,11 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     }
     const long nt128_ = cols / 128;
     const long tiles_big_ = (tri ? nt128_ * (nt128_ + 1) + (rows / 128 - nt128_) * (cols / 64) : (rows / 128) * (cols / 64));
+    // The 128 x 64 form pays from ~1024 tiles per launch on, but only on updates of large objects (the route of the small
+    // ones since the single launch took over the large: batches of <= 1920-point objects are 2-6 % faster on the 64 x 64 form
+    // whatever the tile count, tools/batch_time.py with CGP_BIGTILE).  Both forms sum in the same order: same bits.
     const bool big_form = bulk_cap == 0 &&
-        tiles_big_ * B >= h->env.bigtile;
+        tiles_big_ * B >= h->env.bigtile && (rows >= 2048 || cols >= 2048);
     StageScope sc(h, big_form ? ST_GEMM_BIG : ST_GEMM);
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
