@@ -184,8 +184,14 @@ class Gaussian_process(object):
     def _svd_by_cholesky(self, nugget):
         """May a svd_method=True call be served by the Cholesky route? (see SVD_VIA_CHOLESKY_WHEN_PD)"""
         if SVD_VIA_CHOLESKY_WHEN_PD == 'auto':
-            bound = min(float(np.min(self._diag(sn))) if len(self.y[sn]) else np.inf for sn in range(self.N_sn))
-            return bound + float(nugget) ** 2 > 1e-14
+            # min over every point of y_err**2: a property of the data, cached per identity of the y_err arrays (this is
+            # asked once per objective evaluation: recomputing it cost ten times the device call for 1000 light curves)
+            key = tuple(id(e) for e in self.y_err) if self.y_err is not None else None
+            if getattr(self, '_noise_bound_key', ()) != key:
+                self._noise_bound = min((float(np.min(self._diag(sn))) if len(self.y[sn]) else np.inf
+                                         for sn in range(self.N_sn)), default=np.inf)
+                self._noise_bound_key = key
+            return self._noise_bound + float(nugget) ** 2 > 1e-14
         return bool(SVD_VIA_CHOLESKY_WHEN_PD)
 
     def _res_token(self, sn):
@@ -210,6 +216,7 @@ class Gaussian_process(object):
         self._resident = None
         self._factor_token = None
         self._batch_resident = None
+        self._noise_bound_key = ()
 
     def _my_objects(self):
         if self.comm is None:
@@ -223,6 +230,11 @@ class Gaussian_process(object):
         fit with m prediction points, 3 Np + 128 for the gradient (K, the identity rows, K^-1) -- or
         MAX_BATCH_OBJECTS (the batch index is a grid dimension).  Chunks come largest size first; inside a
         chunk the object order is kept."""
+        # (asked once per objective evaluation: the answer only depends on the lengths of the objects and the limits)
+        key = (tuple(objs), tuple(map(len, self.y)), bool(grad), int(m), BATCH_BYTES_LIMIT, MAX_BATCH_OBJECTS)
+        cached = getattr(self, '_chunks_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         buckets = {}
         for sn in objs:
             buckets.setdefault((len(self.y[sn]) + 127) // 128 * 128, []).append(sn)
@@ -233,6 +245,7 @@ class Gaussian_process(object):
             members = buckets[np_]
             for lo in range(0, len(members), per):
                 chunks.append(members[lo:lo + per])
+        self._chunks_cache = (key, chunks)
         return chunks
 
     def _fit_single(self, sn, kp, nugget, grid=None, new_y0=None, kss_noise=0.):
@@ -290,18 +303,21 @@ class Gaussian_process(object):
             per_obj = [self._fit_single_svd(sn, kp)[0] for sn in objs]
         if self.comm is not None:
             per_obj = self.comm.gather_units(np.asarray(per_obj, dtype=np.float64), self.N_sn)
-        log_likelihood = 0
-        for v in per_obj:                       # object order, like the reference's loop
-            log_likelihood = log_likelihood + np.array([v])
-        self.log_likelihood = log_likelihood
+        total = 0.                              # object order, like the reference's loop (the same float64 additions)
+        for v in per_obj:
+            total = total + float(v)
+        self.log_likelihood = np.array([total]) if len(per_obj) else 0
 
     def _batch_upload(self, chunk):
         """Make `chunk` the resident batch of the handle (skipped when it already is)."""
         dev = self.device
 
         def token():
-            return (dev.batch_generation, tuple(chunk),
-                    tuple((id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn])) for sn in chunk))
+            if len(chunk) == self.N_sn:         # every object, in order: the ids of the three lists' entries at C speed
+                ids = (tuple(map(id, self.y)), tuple(map(id, self.Time)), tuple(map(id, self.y_err)))
+            else:
+                ids = tuple((id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn])) for sn in chunk)
+            return (dev.batch_generation, tuple(chunk), ids)
         if getattr(self, '_batch_resident', None) != token():
             dev.batch_set_data(self._dim, [self.Time[sn] for sn in chunk], [self._resid(sn) for sn in chunk],
                                [self._diag(sn) for sn in chunk])

@@ -93,9 +93,8 @@ class build_pull(object):
             res = pred - y
             self._pull.append(pull)
             self.prediction.append(pred)
-            for t in range(len(y)):
-                self.pull.append(pull[t])
-                self.residual.append(res[t])
+            self.pull.extend(pull)                 # (element by element like pull.py:96-98)
+            self.residual.extend(res)
         self.pull_average, self.pull_std = normal.fit(self.pull)
 
     def _loo_from_full_factor(self, dev, dim, objs, substract_mean):
@@ -134,20 +133,30 @@ class build_pull(object):
                 if np.any(info):
                     b = int(np.nonzero(info)[0][0])
                     raise np.linalg.LinAlgError('matrix of object %d is not positive definite' % part[b][0])
+                # the whole chunk at once on (objects, padded size) arrays; columns beyond an object's n are scratch
+                nb_, npad = len(part), alpha.shape[1]
+                nn = np.array([len(objs[sn][0]) for sn, _ in part])
+                valid = np.arange(npad)[None, :] < nn[:, None]
+                R0, E2, SH = np.zeros((nb_, npad)), np.zeros((nb_, npad)), np.zeros((nb_, npad))
                 for k, (sn, shape) in enumerate(part):
-                    y, x, yerr, dd = objs[sn]
-                    n = len(y)
-                    a, bt, gg, r0 = alpha[k, :n], beta[k, :n], g[k, :n], r0s[k]
-                    if not use_mean:
-                        diff_t = np.zeros(n)
-                    elif dd is None:
-                        diff_t = (np.sum(r0) - r0) / (n - 1.)
-                    else:
-                        diff_t = np.full(n, float(np.ravel(dd)[0]) if np.ndim(dd) else float(dd))
-                    mu = rho * ((r0 - a / gg) - diff_t * (1. - bt / gg))
-                    ktt = kp[0] + (yerr ** 2 + kp[6])
-                    var = np.abs(kss - rho * rho * (ktt - 1. / gg))
-                    out[sn] = (mu + (shape + diff_t if use_mean else 0.), var)
+                    R0[k, :nn[k]] = r0s[k]
+                    E2[k, :nn[k]] = objs[sn][2] ** 2
+                    SH[k, :nn[k]] = shape
+                gg = np.where(valid, g, 1.)
+                if not use_mean:
+                    DT = np.zeros((nb_, npad))
+                else:
+                    DT = (R0.sum(axis=1)[:, None] - R0) / (nn[:, None] - 1.)          # mean over the kept points
+                    for k, (sn, _) in enumerate(part):
+                        dd = objs[sn][3]
+                        if dd is not None:
+                            DT[k, :] = float(np.ravel(dd)[0]) if np.ndim(dd) else float(dd)
+                MU = rho * ((R0 - alpha / gg) - DT * (1. - beta / gg))
+                VAR = np.abs(kss - rho * rho * ((kp[0] + (E2 + kp[6])) - 1. / gg))
+                if use_mean:
+                    MU = MU + (SH + DT)
+                for k, (sn, _) in enumerate(part):
+                    out[sn] = (MU[k, :nn[k]].copy(), VAR[k, :nn[k]].copy())
         return out
 
     def _loo_batched(self, dev, dim, objs, substract_mean):
