@@ -160,8 +160,10 @@ struct cgp_handle {
     std::vector<DagList> dag_lists;
     unsigned long dag_clock = 0;
     DevBuf dstate;
+    DevBuf dsticky;                      // 4 words: the first give-up of any single-launch factorisation since dag_check last looked
     int dag_cus = 0;
-    long dag_groups_ran = 0;             // launches of the last fit whose control words dag_check has to read
+    unsigned sticky_host[4] = {0u, 0u, 0u, 0u};   // host copy of dsticky (a member: it is a pinned-staging destination)
+    bool dag_maybe_ran = false;          // a single-launch factorisation was issued (eagerly or by a graph replay) since dag_check
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
     std::vector<hipEvent_t> fork_events;
@@ -306,7 +308,7 @@ int d2h_2d(cgp_handle* h, void* dst, size_t dpitch, const void* src, size_t spit
 // poll the stream to completion, hand the staged results to the caller, recycle the chunks
 hipError_t stream_sync(cgp_handle* h) {
     const hipError_t e = stream_wait(h->stream);
-    for (auto& o : h->pin_out) {
+    if (e == hipSuccess) for (auto& o : h->pin_out) {
         if (o.rows == 0) std::memcpy(o.dst, o.src, o.bytes);
         else for (size_t r = 0; r < o.rows; ++r) std::memcpy((char*)o.dst + r * o.dpitch, (const char*)o.src + r * o.spitch, o.width);
     }
@@ -323,6 +325,14 @@ int fail(cgp_handle* h, int code, const char* msg) {
     h->err = msg;
     return code;
 }
+
+// Staged device -> host results that were never delivered belong to a call that failed between queueing them and its
+// synchronisation: their destinations (that call's stack, its caller's arrays) may be gone.  Every entry point starts here.
+void drop_stale_staging(cgp_handle* h) {
+    h->pin_out.clear();
+    if (!h->pin.empty()) h->pin.back().used = 0;
+}
+
 
 int ensure(cgp_handle* h, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return 0;
@@ -716,9 +726,10 @@ int cgp_destroy(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
     (void)cgp_comm_destroy(h);
     (void)hipSetDevice(h->device);
+    drop_stale_staging(h);
     (void)stream_sync(h);
     for (auto& l : h->dag_lists) { free_buf(l.tasks); free_buf(l.state0); }
-    DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
+    DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->dsticky, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
@@ -739,6 +750,7 @@ const char* cgp_last_error(cgp_handle* h) { return h ? h->err.c_str() : "null ha
 
 int cgp_synchronize(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
+    drop_stale_staging(h);
     HIPCHK(stream_sync(h));
     return CGP_OK;
 }
@@ -750,6 +762,7 @@ namespace {
 int begin_call(cgp_handle* h) {
     if (!h) return CGP_E_ARG;
     h->err.clear();
+    drop_stale_staging(h);
     HIPCHK(hipSetDevice(h->device));
     CHK(leaf_attr_once(h));
     CHK(ensure(h, h->bkp, CGP_MAX_SWEEP * sizeof(KParams)));   // [0] = the shared set; a sweep uses one per candidate
@@ -942,6 +955,13 @@ int dag_build(cgp_handle* h, const Prob& P) {
         HIPCHK(hipGetDeviceProperties(&prop, h->device));
         h->dag_cus = prop.multiProcessorCount;
     }
+    if (!h->dsticky.p) {
+        CHK(ensure(h, h->dsticky, 4 * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(h->dsticky.p, 0, 4 * sizeof(unsigned), h->stream));
+    }
+    // every caller of dag_build goes on to issue the launches (directly, by capturing them, or by replaying the graph that
+    // holds them), so this is the one place that knows a give-up may have to be reported
+    h->dag_maybe_ran = true;
     const long nb = P.Np / NB, nr = P.R / NB;
     long per, ngroups;
     dag_groups(h, P, per, ngroups);
@@ -986,6 +1006,7 @@ int launch_dag(cgp_handle* h, Prob& P) {
         dp.tasks = (const int4*)l->tasks.p; dp.ntasks = l->ntasks;
         dp.ctrl = (unsigned*)h->dstate.p + 8 * g;
         dp.state = (unsigned*)h->dstate.p + 8 * ngroups + g * sw;
+        dp.sticky = (unsigned*)h->dsticky.p;
         dp.wsW = P.wsW + b0 * P.sW; dp.ldp = P.ldp + b0 * P.sLd; dp.info = P.info + b0;
         dp.timeout = (long long)h->env.dag_timeout_ms * 100000ll;           // wall_clock64 runs at 100 MHz
         dp.dbg = 0;
@@ -994,25 +1015,27 @@ int launch_dag(cgp_handle* h, Prob& P) {
         HIPCHK(hipGetLastError());
         if (h->profiling) h->gemm_launches++;          // stage report [6]: launches of the dominant kernel
     }
-    h->dag_groups_ran = ngroups;
     return 0;
 }
 
-// after a synchronised fit: did a single-launch factorisation give up (bounded spins)?
-int dag_check(cgp_handle* h) {
-    if (!h->dag_groups_ran) return 0;
-    const long ng = h->dag_groups_ran;
-    h->dag_groups_ran = 0;
-    std::vector<unsigned> c((size_t)ng * 8, 0u);
-    CHK(d2h(h, c.data(), h->dstate.p, c.size() * sizeof(unsigned)));
+// The synchronisation at the end of a fit + did any single-launch factorisation since the last look give up (bounded
+// spins)?  The launches leave their first give-up in the handle's sticky words (dag_note_abort), which no launch clears: a
+// replayed graph, the chunks of a sharded sweep and the repetitions of the bench entry points are all covered by ONE read,
+// which travels with the call's other results (no second synchronisation).
+int sync_and_check(cgp_handle* h) {
+    const bool look = h->dag_maybe_ran && h->dsticky.p;
+    h->dag_maybe_ran = false;
+    if (look) CHK(d2h(h, h->sticky_host, h->dsticky.p, sizeof(h->sticky_host)));
     HIPCHK(stream_sync(h));
-    for (long g = 0; g < ng; ++g)
-        if (c[8 * g + 1] != 0) {
-            char msg[200];
-            snprintf(msg, sizeof(msg), "single-launch factorisation gave up (launch %ld of %ld: abort %u, wait code 0x%x, ticket %u, leaf stamp %u)",
-                     g, ng, c[8 * g + 1], c[8 * g + 2], c[8 * g], c[8 * g + 3]);
-            return fail(h, CGP_E_HIP, msg);
-        }
+    if (look && h->sticky_host[0] != 0) {
+        const unsigned* c = h->sticky_host;
+        char msg[200];
+        snprintf(msg, sizeof(msg), "single-launch factorisation gave up (abort %u, wait code 0x%x, ticket %u, leaf stamp %u)",
+                 c[0], c[1], c[2], c[3]);
+        HIPCHK(hipMemsetAsync(h->dsticky.p, 0, sizeof(h->sticky_host), h->stream));
+        HIPCHK(stream_sync(h));
+        return fail(h, CGP_E_HIP, msg);
+    }
     return 0;
 }
 
@@ -1204,8 +1227,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
         CHK(d2h(h, mu, P.mu, m * sizeof(double)));
         if (var) CHK(d2h(h, var, P.var, m * sizeof(double)));
     }
-    HIPCHK(stream_sync(h));
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
@@ -1289,8 +1311,7 @@ int cgp_fit_grad(cgp_handle* h, const double* kp, const double* diag, double* lo
     CHK(d2h(h, sc, P.scal, 2 * sizeof(double)));
     CHK(d2h(h, &info, P.info, sizeof(int)));
     CHK(d2h(h, sums, h->bgrad.p, 5 * sizeof(double)));
-    HIPCHK(stream_sync(h));
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     if (loglik) *loglik = sc[0];
     if (logdet) *logdet = sc[1];
     h->factored = (info == 0);
@@ -1339,8 +1360,7 @@ int cgp_batch_fit_grad(cgp_handle* h, const double* kp, double* loglik, int32_t*
     CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
     CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
     CHK(d2h(h, gs.data(), h->bgrad.p, gs.size() * sizeof(double)));
-    HIPCHK(stream_sync(h));
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1413,8 +1433,7 @@ int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, 
     CHK(d2h_2d(h, alpha, Np * sizeof(double), h->qmu.p, tall * sizeof(double), Np * sizeof(double), B));
     CHK(d2h_2d(h, beta, Np * sizeof(double), h->bout.p, tall * sizeof(double), Np * sizeof(double), B));
     CHK(d2h_2d(h, g, Np * sizeof(double), h->qvar.p, tall * sizeof(double), Np * sizeof(double), B));
-    HIPCHK(stream_sync(h));
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     if (info) for (long b = 0; b < B; ++b) info[b] = hinfo[b];
     h->last_was_batch = false;           // the batch's matrices now hold this layout: cgp_bench_fit must not replay a fit on them
     return CGP_OK;
@@ -1818,8 +1837,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
         if (var)
             CHK(d2h_2d(h, var, m * sizeof(double), Q.var, Mp * sizeof(double), m * sizeof(double), B));
     }
-    HIPCHK(stream_sync(h));
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     for (long b = 0; b < B; ++b) {
         if (loglik) loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -1897,7 +1915,7 @@ int cgp_sweep_loglik(cgp_handle* h, int64_t np_, const double* kp, const double*
     std::vector<int> hinfo(B);
     CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
     CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
-    HIPCHK(stream_sync(h));
+    CHK(sync_and_check(h));
     for (long b = 0; b < B; ++b) {
         loglik[b] = sc[2 * b];
         if (info) info[b] = hinfo[b];
@@ -2091,7 +2109,7 @@ int cgp_sweep_loglik_sharded(cgp_handle* h, int64_t np_total, const double* kp, 
     NCCLCHK(R->AllGather(h->csend.p, h->crecv.p, (size_t)per * 2, ncclDouble, h->comm, h->stream));
     std::vector<double> all((size_t)per * 2 * W);
     CHK(d2h(h, all.data(), h->crecv.p, all.size() * sizeof(double)));
-    HIPCHK(stream_sync(h));
+    CHK(sync_and_check(h));
     for (long q = 0; q < W; ++q)
         for (long u = lo_of(q); u < lo_of(q + 1); ++u) {
             const double* e = &all[(size_t)(q * per + (u - lo_of(q))) * 2];
@@ -2147,7 +2165,7 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
     *ms_per_fit = (double)ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     if (stage_ms) {
         for (int i = 0; i < 12; ++i) stage_ms[i] = 0.;
         h->profiling = true;
@@ -2198,7 +2216,7 @@ int cgp_bench_fit_objects(cgp_handle* h, int iters, int64_t nobj, double* ms_per
     *ms_per_pass = (double)ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    CHK(dag_check(h));
+    CHK(sync_and_check(h));
     return CGP_OK;
 }
 

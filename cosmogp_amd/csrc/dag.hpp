@@ -43,6 +43,8 @@ struct DagParams {
     int ntasks;
     unsigned* state;        // [nmat][nr * nb]
     unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)  [3] progress of leaf lane 0
+    unsigned* sticky;       // [0] abort code  [1] failing wait  [2] ticket head then: the FIRST give-up of any launch on this handle since
+                            // the host last looked (never reset by a launch: graph replays and chunked sequences reuse `ctrl`)
     double* wsW;            // [nb][8][256] T^-T blocks of the diagonal tiles (also read by later solves)
     double* ldp;            // [nb] logdet parts
     int* info;
@@ -652,6 +654,21 @@ __device__ void dag_leaf(const DagParams& p, double* smem, int b) {
     if (b == 0) dag_stamp(p.ctrl, 0xffffu);
 }
 
+// A lane that leaves after a give-up (its own or another lane's) copies the launch's abort words into the handle's sticky
+// words, first give-up wins: `ctrl` is cleared by the next launch (graph replays, chunked sequences), the sticky words only
+// by the host once it has reported them (dag_check).
+__device__ __forceinline__ void dag_note_abort(const DagParams& p) {
+    if (threadIdx.x != 0 || !p.sticky) return;
+    const unsigned ab = dag_ld_flag(p.ctrl + 1);
+    if (ab == 0) return;
+    unsigned exp0 = 0u;
+    if (__hip_atomic_compare_exchange_strong((gu32*)p.sticky, &exp0, ab, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        dag_st_flag(p.sticky + 1, dag_ld_flag(p.ctrl + 2));
+        dag_st_flag(p.sticky + 2, dag_ld_flag(p.ctrl));
+        dag_st_flag(p.sticky + 3, dag_ld_flag(p.ctrl + 3));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------------
@@ -660,6 +677,7 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
     int* cw = (int*)(smem + DAG_LDS_DOUBLES);       // [0] wait result, [1..5] ticket + descriptor
     if ((int)blockIdx.x < p.nmat) {
         if (p.dbg != 9) dag_leaf(p, smem, (int)blockIdx.x);   // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
+        dag_note_abort(p);
         return;
     }
     const int nb = p.nb;
@@ -701,4 +719,5 @@ __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
         w[0] = acc_wait; w[1] = acc_trsm; w[2] = acc_upd; w[3] = acc_n | ((unsigned long long)(acc_wt / 16) << 20) | ((unsigned long long)(acc_w1 / 16) << 42);
     }
     if (p.dbg >= 5 && threadIdx.x == 0) dag_st_flag(p.ctrl + 5, 0x4000u);
+    dag_note_abort(p);
 }

@@ -287,3 +287,38 @@ def test_dag_gradient_default_route_at_4096(monkeypatch):
     np.testing.assert_allclose(got[1][2], ref[1][2], rtol=1e-8, atol=1e-8)
     for q in range(3):
         np.testing.assert_allclose(got[2][q][0], ref[2][q][0], rtol=1e-8, atol=1e-9)
+
+
+def test_dag_give_up_is_reported_on_first_and_replayed_calls(monkeypatch):
+    """A bounded spin that gives up (forced: CGP_DAG_TIMEOUT_MS=0 makes the first unsatisfied poll of any lane give up) must
+    come back as an error of the call -- on the eager / capturing first call of a shape, on the graph REPLAYS after it (the
+    launch's own control words are cleared by every launch; the handle's sticky words keep the first give-up), and on the
+    sweep entry point, which shares the route -- never as CGP_OK with unfinished numbers.  (round-2 advisor finding)"""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    x, y, e, _ = _problem(2048, 0, 77, 1)
+    for k in ('CGP_NO_DAG', 'CGP_NO_GRAPH', 'CGP_DAG_GRID', 'CGP_NO_DAG_BATCH'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('CGP_DAG_MIN_NB', '2')
+    monkeypatch.setenv('CGP_DAG_BATCH_MIN_NB', '2')
+    monkeypatch.setenv('CGP_DAG_TIMEOUT_MS', '0')
+    dev = _lib.Device(0)
+    kp = K.kernel_params_1d([1., 2.])
+    dev.set_data(1, x, y)
+    dg = K.diag_term(len(y), e, 0., 0.)
+    for call in range(3):               # capture, replay, replay
+        with pytest.raises(_lib.HipError, match='gave up'):
+            dev.fit(kp, dg, None, None, 0.)
+    kps = np.stack([K.kernel_params_1d([1., 2.]), K.kernel_params_1d([0.9, 2.5]), K.kernel_params_1d([1.1, 1.5])])
+    for call in range(2):
+        with pytest.raises(_lib.HipError, match='gave up'):
+            dev.sweep_loglik(kps, dg)
+    dev.close()
+    # the same handle type with the default bound: same inputs, a result
+    monkeypatch.delenv('CGP_DAG_TIMEOUT_MS')
+    dev = _lib.Device(0)
+    dev.set_data(1, x, y)
+    ll = dev.fit(kp, dg, None, None, 0.)[0]
+    ll2, info = dev.sweep_loglik(kps, dg)
+    dev.close()
+    assert np.isfinite(ll) and info[0] == 0 and abs(ll2[0] - ll) <= 1e-11 * abs(ll)

@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
     if (dbg == 9) { std::vector<unsigned> big(nr * nb, 100000u); CK(hipMemcpy(dS + 8, big.data(), big.size() * 4, hipMemcpyHostToDevice)); }
     CK(hipFuncSetAttribute((const void*)k_chol_dag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DAG_LDS_BYTES));
     DagParams p;
+    p.sticky = nullptr;
     p.nmat = dbg == 9 ? 1 : nmat; p.sM = (long)A.size(); p.sW = (long)nb * 2048; p.sLd = nb;
     p.M = dA; p.ld = ld; p.nb = nb; p.nr = nr; p.tasks = dT; p.ntasks = (int)t.size(); p.ctrl = dS; p.state = dS + 8;
     unsigned long long* dP; const size_t nprof = (size_t)nb * 8 + (size_t)grid * 4 + 8;
