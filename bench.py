@@ -38,7 +38,7 @@ SPEC_FP64_MFMA_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (AMD
 SPEC_HBM_GBS = 8000.0
 
 
-def make_workload(name, rank=0, obj=0):
+def make_workload(name, rank=0, obj=0, nobj=128):
     from cosmogp_amd import kernel as K
     if name == 'c3':
         rng = np.random.default_rng(3 + 1000 * rank + 37 * obj)
@@ -60,7 +60,7 @@ def make_workload(name, rank=0, obj=0):
                     xnew=np.random.default_rng(20 + 1000 * rank).uniform(0., 400., m), hyp=hyp,
                     kp=K.kernel_params_1d(hyp), label='1D RBF GP N=4096 M=1024 (BASELINE config[1])')
     if name == 'c4':
-        B, n, m = 128, 512, 19
+        B, n, m = int(nobj), 512, 19
         xs, ys, es = [], [], []
         for i in range(B):
             rng = np.random.default_rng(4000 + i + 1000 * rank)
@@ -72,7 +72,7 @@ def make_workload(name, rank=0, obj=0):
         hyp = [0.5, 8.]
         return dict(dim=1, n=n, m=m, B=B, xs=xs, ys=ys, es=es, xnew=np.linspace(-12., 42., m), hyp=hyp,
                     kp=K.kernel_params_1d(hyp),
-                    label='128 x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3] / 8)')
+                    label='%d x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3]: 1024 over 8 GPUs)' % B)
     if name == 'c5':
         rng = np.random.default_rng(5)                      # same field on every rank, pairs differ
         n = 16384
@@ -225,14 +225,17 @@ def cpu_baseline(wl):
 
     nw_ = max(256, ns_ // 8)
     full_fit(xs_[:nw_], ys_[:nw_], es_[:nw_], record=False)        # warm-up (BLAS threads, page faults) at N/8
-    best, reps = _best_of(full_fit, 5, 10.0)
+    best, reps = _best_of(full_fit, 5, 26.0)
     # a reduced sample is scaled stage by stage: assembly ~ N^2, factor / solve ~ N^3
     est = stage['assembly'] * (n / float(ns_)) ** 2 + stage['factor_solve'] * scale
+    cap = ('' if threads >= info['physical_cores'] else
+           '; BLAS threads = %d of %d physical cores: the thread cap of this OpenBLAS build, every thread it offers is used'
+           % (threads, info['physical_cores']))
     out = dict(value=1.0 / est, unit='fits/s', cores=threads, kind='port', seconds=round(best, 3),
-               sample=('%s at N=%d%s: assembly %.2f s + cho_factor/cho_solve%s %.2f s; best of %d after a warm-up'
+               sample=('%s at N=%d%s: assembly %.2f s + cho_factor/cho_solve%s %.2f s; best of %d after a warm-up%s'
                        % ('1 log-likelihood' if sweep else '1 full fit of the workload', ns_,
                           (' scaled to N=%d (assembly x %.0f, factorisation x %.0f)' % (n, (n / float(ns_)) ** 2, scale))
-                          if scale > 1 else '', stage['assembly'], '' if sweep else '/predict', stage['factor_solve'], reps)))
+                          if scale > 1 else '', stage['assembly'], '' if sweep else '/predict', stage['factor_solve'], reps, cap)))
     # ONE BLAS thread: at a quarter of the size (the full size would take minutes), scaled by the N^3 law
     n1 = max(512, ns_ // 4)
     one = one_thread(lambda: full_fit(xs_[:n1], ys_[:n1], es_[:n1], record=False))
@@ -266,7 +269,66 @@ def cpu_baseline(wl):
     return out
 
 
-def launch_ranks(n_gpus):
+def multi_gpu_extras(dev, comm, rank, world, local_rank, args):
+    """BASELINE configs 4 and 5 are defined over the GPUs of a node: under --gpus N every rank also times its share of
+    them -- 1024 / N light curves (N = 512, M = 19) per pass through cgp_batch_fit's resident path, and the 32-candidate
+    log-likelihood sweep at N = 16384 through cgp_sweep_loglik_sharded (each rank factors 32 / N candidates, ONE
+    ncclAllGather inside the library) -- between barriers, max over ranks; whole-job rates go to rank 0's line."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    out = {}
+    if comm is None:
+        return out
+
+    def timed(fn, reps):
+        fn()                                  # warm-up (graph capture, workspaces)
+        comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        comm.barrier()
+        return comm.allreduce_max(time.perf_counter() - t0) / reps
+
+    try:
+        # ---- config 4: 1024 light curves over the ranks, contiguous blocks
+        per = 1024 // world
+        w4 = make_workload('c4', rank, nobj=per)
+        d4 = _lib.Device(local_rank)
+        diags = [K.diag_term(w4['n'], e, 0., 0.) for e in w4['es']]
+        ll, info, mu, var = d4.batch_fit(1, w4['xs'], w4['ys'], diags, w4['kp'], w4['xnew'], None, 0.)
+        assert not info.any()
+        dt = timed(lambda: d4.bench_fit(4, stages=False), 3) / 4
+        g = comm._allgather(np.stack([mu.ravel(), var.ravel()]))           # the one gather of the path
+        out['c4'] = dict(fits_per_sec=round(world * per / dt, 1), fits_per_rank_per_pass=per, ms_per_pass=round(dt * 1e3, 4),
+                         gathered_shape=list(g.shape), note='1024 x (N=512, M=19) over %d ranks, device-resident passes' % world)
+        d4.close()
+    except Exception as exc:                                               # reported, never fatal for the headline
+        out['c4'] = dict(error=repr(exc)[:300])
+    try:
+        # ---- config 5: 32 (sigma, l) candidates at N = 16384 over the ranks
+        w5 = make_workload('c5', 0)
+        sig = np.logspace(-0.5, 0.5, 4)
+        ell = np.logspace(1.5, 2.5, 8)
+        kps = np.array([K.kernel_params_2d([s_, l_, l_, 0.], sigma2_in_train=True) for s_ in sig for l_ in ell])
+        if comm.backend != 'rccl':
+            raise RuntimeError('needs the RCCL communicator of the library (cgp_sweep_loglik_sharded)')
+        dev.set_data(w5['dim'], w5['x'], w5['y'])
+        dg = K.diag_term(w5['n'], w5['e'], 0., 0.)
+        res = {}
+
+        def sweep():
+            res['ll'], res['info'] = dev.sweep_loglik_sharded(kps, dg, chunk=4)
+        dt = timed(sweep, 1)
+        assert not res['info'].any() and np.all(np.isfinite(res['ll']))
+        out['c5'] = dict(candidates_per_sec=round(len(kps) / dt, 3), seconds_per_sweep=round(dt, 4), candidates=len(kps),
+                         candidates_per_rank=-(-len(kps) // world),
+                         note='32 log-likelihoods of the 2D N=16384 object over %d ranks (cgp_sweep_loglik_sharded)' % world)
+    except Exception as exc:
+        out['c5'] = dict(error=repr(exc)[:300])
+    return {'multi_gpu': out}
+
+
+def launch_ranks(n_gpus, script=None, argv=None):
     """`python bench.py --gpus N` run plainly: start N ranks (one per GPU) as child processes BEFORE anything in
     this process touches the GPU, pass rank 0's JSON line through, return the worst exit code.  A rank that dies takes
     the others with it (they would wait for it inside the collective for ever)."""
@@ -280,8 +342,8 @@ def launch_ranks(n_gpus):
     for r in range(n_gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), CGP_BENCH_CHILD='1')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv),
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     import threading
     out = []
     reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()))
@@ -404,18 +466,27 @@ def main():
     dev.selftest_mfma()
     comm = None
     collective = None
+    rccl_ranks = None
     if world > 1 or 'RANK' in os.environ:          # launched as a rank (any world size): RCCL inside the library
         from cosmogp_amd import multigpu
-        try:
-            if os.environ.get('CGP_BENCH_COMM') == 'file':
-                raise RuntimeError('CGP_BENCH_COMM=file')
-            comm = multigpu.Comm(dev, rank=rank, world=world)
-            collective = 'RCCL inside the library (cgp_comm_*: ncclAllGather / ncclAllReduce on the handle\'s stream)'
-        except Exception as exc:                   # measured all the same, and labelled
-            print('rank %d: RCCL communicator failed (%s): files in the temporary directory instead' % (rank, exc),
-                  file=sys.stderr)
+        if os.environ.get('CGP_BENCH_COMM') == 'file':
+            # asked for explicitly (a debugging aid, e.g. on a box whose RCCL cannot start): never chosen silently
             comm = FileComm(rank, world)
-            collective = 'FILE FALLBACK (RCCL communicator failed: %s)' % str(exc)[:200]
+            collective = 'FILE STAND-IN (CGP_BENCH_COMM=file): not RCCL'
+            rccl_ranks = None
+        else:
+            try:
+                comm = multigpu.Comm(dev, rank=rank, world=world)
+            except Exception as exc:
+                # a multi-rank number that did not go through RCCL is not the measurement the contract asks for: fail
+                print('rank %d: RCCL communicator failed (%s); set CGP_BENCH_COMM=file to run with the file stand-in'
+                      % (rank, exc), file=sys.stderr)
+                sys.exit(3)
+            rccl_ranks = comm.ranks_reported           # ncclCommCount
+            if rccl_ranks != world:
+                print('rank %d: RCCL reports %d ranks, launched with %d' % (rank, rccl_ranks, world), file=sys.stderr)
+                sys.exit(3)
+            collective = 'RCCL inside the library (cgp_comm_*: ncclAllGather / ncclAllReduce on the handle\'s stream)'
     wl = make_workload(args.workload, rank)
     batched = 'B' in wl
     # Batches of objects with >= 16 tile columns (N >= 2048) are factored by ONE persistent launch per group of objects
@@ -483,7 +554,9 @@ def main():
                 d.set_data(wl['dim'], wl['x'], wl['y'])
                 out = d.fit(wl['kp'], diag, wl['xnew'], None, 0.)
                 assert out[0] == ll and np.array_equal(out[2], mu)          # every handle computes the same fit
-        units_per_step = 1
+        # a step = one pass over the objects of a launch sequence (`lock` distinct objects, one persistent launch): every
+        # step of the timed region is then the same launch shape (round 2 counted single fits and ended on a partial pass)
+        units_per_step = lock
 
     def sync_all():
         for d in set([dev] + extra_devs + (fit_devs if (lock > 1 and 'sweep' not in wl) else [])):
@@ -514,11 +587,7 @@ def main():
             for i in range(k):
                 d.fit(kps[(offset + i) % len(kps)], None)
         elif k > 0 and lock > 1:
-            # k fits = k // lock passes over the whole resident batch + one pass over the first k % lock objects
-            if k // lock:
-                d.bench_fit_objects(k // lock, lock)
-            if k % lock:
-                d.bench_fit_objects(1, k % lock)
+            d.bench_fit_objects(k, lock)          # k passes over the whole resident batch
         elif k > 0:
             d.bench_fit(k, stages=False)
 
@@ -537,12 +606,6 @@ def main():
         for t in ths:
             t.join()
 
-    if lock > 1 and 'sweep' not in wl:
-        # capture the launch graph of the partial pass each handle will need (k % lock objects) outside the timed region
-        for i, d in enumerate(all_devs):
-            k_i = args.steps // len(all_devs) + (1 if i < args.steps % len(all_devs) else 0)
-            if k_i % lock:
-                d.bench_fit_objects(1, k_i % lock)
     run_steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()
@@ -573,7 +636,7 @@ def main():
             flops = nobj_pass * (float(n) ** 3 / 3.0 + float(n) ** 2 * (wl.get('m', 0) + 1))
         ach = flops / (gemm_ms * 1e-3) / 1e12
         traffic, tsrc = None, None
-        for rnd in ('r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
+        for rnd in ('r03', 'r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
             tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json'
                                  % (rnd, args.workload, ('_single' if nobj_pass == 1 else '_dagbatch') if dag else ''))
             if os.path.exists(tpath):
@@ -645,6 +708,30 @@ def main():
                                   note='one fit at a time on one handle (no lock-step batch, no second stream): full fit '
                                        'latency, and N^3/3 flops over the wall time of a log-likelihood-only fit '
                                        '(assembly + blocked Cholesky with one residual row)')
+    if not batched and not args.no_extras and args.workload == 'c3' and roof is not None:
+        # the N = 4096 half of BASELINE.json's metric ("single-fit Cholesky GF/s at N=4096/8192"): the first 4096 points of
+        # the same object, one log-likelihood-only fit at a time on a handle of its own, and its full fit (M = 2500)
+        n4 = 4096
+        d4 = _lib.Device(local_rank)
+        d4.set_data(wl['dim'], wl['x'][:n4], wl['y'][:n4])
+        dg4 = K.diag_term(n4, wl['e'][:n4], 0., 0.)
+        d4.fit(wl['kp'], dg4)
+        d4.bench_fit(2, stages=False)
+        t_c = time.perf_counter()
+        d4.bench_fit(8, stages=False)
+        c4_ms = (time.perf_counter() - t_c) * 1e3 / 8
+        d4.fit(wl['kp'], dg4, wl['xnew'], None, 0.)
+        d4.bench_fit(2, stages=False)
+        t_c = time.perf_counter()
+        d4.bench_fit(5, stages=False)
+        f4_ms = (time.perf_counter() - t_c) * 1e3 / 5
+        d4.close()
+        g4 = n4 ** 3 / 3.0 / (c4_ms * 1e-3) / 1e9
+        extra['single_fit_n4096'] = dict(latency_ms=round(f4_ms, 4), cholesky_ms=round(c4_ms, 4), cholesky_gflops=round(g4, 1),
+                                         frac=round(g4 / 1e3 / SPEC_FP64_MFMA_TFLOPS, 4),
+                                         note='2D RBF GP, the first 4096 points of the same object: N^3/3 flops over the wall time '
+                                              'of a log-likelihood-only fit; latency_ms = its full fit with M = 2500')
+        roof['single_fit_n4096'] = extra['single_fit_n4096']
     if not args.no_extras and 'sweep' not in wl:
         # API-level rate, the SURVEY.md 8(d) definition of a fit: host arrays in -> device -> mu / var / loglik on the
         # host (PCIe-inclusive; it is never `value`)
@@ -685,6 +772,11 @@ def main():
                                      'api_single_*: cgp_fit_set_data + cgp_fit of one object' % lock)
             else:
                 extra['api_fits_per_sec'] = extra['api_single_fits_per_sec']
+    if roof is not None and 'api_fits_per_sec' in extra:
+        # SURVEY.md 8(d) counts a fit from host arrays in to results on the host: that rate, next to the device-resident `value`
+        roof['api_fits_per_sec'] = extra['api_fits_per_sec']
+    if world > 1 or 'RANK' in os.environ:
+        extra.update(multi_gpu_extras(dev, comm, rank, world, local_rank, args))
     if rank == 0:
         if extra.get('assemble_K_GBs'):
             # second roofline object: the covariance build (K1), HBM-write bound by its algorithmic bytes
@@ -710,7 +802,11 @@ def main():
                                 fits_per_step_per_gpu=units_per_step,
                                 fits_in_flight_per_gpu=nstreams * (wl['B'] if batched else lock),
                                 objects_per_launch_sequence=(wl['B'] if batched else lock), handles_per_gpu=nstreams,
-                                collective=collective,
+                                collective=collective, rccl_ranks=rccl_ranks,
+                                value_definition='device-resident fits/s: every input already in HBM when the timed region starts, '
+                                                 'results left in HBM (the contract of bench.py); roofline.api_fits_per_sec is the '
+                                                 'SURVEY.md 8(d) rate of the same workload: host arrays in, mu / var / loglik back on '
+                                                 'the host, PCIe included',
                                 factorisation_route=('single launch: persistent tile-DAG kernel k_chol_dag, one leaf lane per object'
                                                      if (roof is not None and 'k_chol_dag' in roof['kernel'])
                                                      else 'one launch per step: k_potrf_diag / k_trsm_panel / k_gemm_nt'),

@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
     'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
     'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_batch_loo', 'cgp_sweep_loglik',
-    'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_allgather', 'cgp_comm_allreduce',
+    'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_count', 'cgp_comm_allgather', 'cgp_comm_allreduce',
     'cgp_sweep_loglik_sharded', 'cgp_bispev', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
     'cgp_selftest_mfma',
 )
@@ -81,6 +81,7 @@ def load_library():
         lib.cgp_comm_unique_id.argtypes = [ctypes.c_char_p]
         lib.cgp_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
         lib.cgp_comm_destroy.argtypes = [vp]
+        lib.cgp_comm_count.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
         lib.cgp_comm_allgather.argtypes = [vp, _dp, _i64, _dp]
         lib.cgp_comm_allreduce.argtypes = [vp, _dp, _i64, ctypes.c_int]
         lib.cgp_sweep_loglik_sharded.argtypes = [vp, _i64, _dp, _dp, _i64, _dp, ctypes.POINTER(ctypes.c_int32)]
@@ -400,6 +401,12 @@ class Device(object):
 
     def comm_destroy(self):
         self._check(self._lib.cgp_comm_destroy(self._h), 'cgp_comm_destroy')
+
+    def comm_count(self):
+        """Ranks the RCCL communicator of this handle reports (ncclCommCount)."""
+        c = ctypes.c_int(0)
+        self._check(self._lib.cgp_comm_count(self._h, ctypes.byref(c)), 'cgp_comm_count')
+        return int(c.value)
 
     def comm_allgather(self, send):
         """send: float64 array of the same size on every rank; returns (world, send.size)."""

@@ -1935,6 +1935,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1954,6 +1955,7 @@ Rccl* rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -2034,6 +2036,15 @@ int cgp_comm_destroy(cgp_handle* h) {
     h->comm_world = 1;
     h->comm_rank = 0;
     NCCLCHK(R->CommDestroy(c));
+    return CGP_OK;
+}
+
+int cgp_comm_count(cgp_handle* h, int* ranks) {
+    CHK(begin_call(h));
+    Rccl* R;
+    CHK(comm_ready(h, R));
+    if (!ranks) return fail(h, CGP_E_ARG, "cgp_comm_count: bad argument");
+    NCCLCHK(R->CommCount(h->comm, ranks));
     return CGP_OK;
 }
 

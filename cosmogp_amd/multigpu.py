@@ -103,8 +103,16 @@ def _id_file(port):
     base = os.environ.get('CGP_COMM_ID_FILE')
     if base:
         return base
-    # every rank of one job has the same parent (torch.distributed.run's agent, or bench.py's launcher)
-    return os.path.join(tempfile.gettempdir(), 'cgp_rccl_id_%d_%s_%d' % (os.getuid(), port, os.getppid()))
+    # every rank of one job has the same parent (torch.distributed.run's agent, or bench.py's launcher): its pid AND its
+    # start time are in the name, so a file left behind by a crashed job (another launcher process, even one that got the
+    # same pid and port) can never be read as this job's id
+    ppid = os.getppid()
+    try:
+        with open('/proc/%d/stat' % ppid) as f:
+            born = f.read().rsplit(')', 1)[1].split()[19]          # field 22: start time of the process, in clock ticks
+    except (OSError, IndexError):
+        born = '0'
+    return os.path.join(tempfile.gettempdir(), 'cgp_rccl_id_%d_%s_%d_%s' % (os.getuid(), port, ppid, born))
 
 
 def exchange_unique_id(rank, world, make_id, timeout=300.):
@@ -114,6 +122,10 @@ def exchange_unique_id(rank, world, make_id, timeout=300.):
         return make_id(), path
     if rank == 0:
         uid = make_id()
+        try:
+            os.unlink(path)                    # (a second communicator of the same job: never leave the first id readable)
+        except OSError:
+            pass
         tmp = '%s.tmp.%d' % (path, os.getpid())
         with open(tmp, 'wb') as f:
             f.write(uid)
@@ -149,6 +161,7 @@ class Comm(CommBase):
         uid, path = exchange_unique_id(self.rank, self.world, _lib.comm_unique_id)
         self.device.comm_init(self.rank, self.world, uid)
         self.backend = 'rccl'
+        self.ranks_reported = self.device.comm_count()      # what RCCL itself says (bench.py records it: config.rccl_ranks)
         self.barrier()                       # every rank has read the id: rank 0 may remove the file
         if self.rank == 0 and self.world > 1:
             try:

@@ -193,6 +193,8 @@ enum { CGP_OP_SUM = 0, CGP_OP_MAX = 1 };
 int cgp_comm_unique_id(void* id_out);                                  /* CGP_COMM_ID_BYTES bytes */
 int cgp_comm_init(cgp_handle* h, int rank, int world, const void* id); /* collective over all ranks */
 int cgp_comm_destroy(cgp_handle* h);
+/* ranks the communicator itself reports (ncclCommCount): what a caller records to show that RCCL really spans `world` ranks */
+int cgp_comm_count(cgp_handle* h, int* ranks);
 /* recv[world][count] <- send[count] of every rank (host pointers, staged through HBM, ncclAllGather) */
 int cgp_comm_allgather(cgp_handle* h, const double* send, int64_t count, double* recv);
 /* buf[count] <- elementwise sum / max over ranks (ncclAllReduce); count = 0 is a barrier */

@@ -315,5 +315,82 @@ def main():
          pull_submean=np.array(bs.pull), residual_submean=np.array(bs.residual))
 
 
+def main_round3():
+    """Fixtures added in round 3 (own seed: the files of main() are not rewritten): a 2D fit, 2D and ragged n-object
+    leave-one-out pulls, and the svd_method=True route on a noise-free (numerically singular) matrix whose spectrum crosses
+    the reference's 1e-15 threshold far above the rounding noise of the decomposition."""
+    ref = load_reference()
+    rng = np.random.default_rng(20261005)
+
+    # ---------------- a8 in 2D: find_hyperparameters (N = 100) -----------
+    X = rng.uniform(0., 20., (100, 2))
+    e = np.full(100, 0.1)
+    hyp_true = np.array([1.0, 3.0, 2.0, 1.5])
+    with quiet():
+        Kt = ref.rbf_kernel_2d(X, hyp_true, y_err=e)
+    yv = np.linalg.cholesky(Kt) @ rng.standard_normal(100)
+    g2 = ref.gaussian_process(yv, X, kernel='RBF2D', y_err=e)
+    guess = np.array([1.0, 2.5, 2.5, 0.5])
+    with quiet():
+        g2.find_hyperparameters(hyperparameter_guess=guess.copy(), svd_method=False)
+        fit_hyp = np.array(g2.hyperparameters, dtype=float)
+        g2.compute_log_likelihood(fit_hyp, svd_method=False)
+        ll_fit = float(g2.log_likelihood[0])
+        g2.compute_log_likelihood(guess, svd_method=False)
+        ll_guess = float(g2.log_likelihood[0])
+    save('fit_2d_n100', x=X, y=yv, e=e, guess=guess, fit_hyp=fit_hyp, loglik_at_fit=ll_fit, loglik_at_guess=ll_guess)
+
+    # ---------------- pull.py in 2D (N = 20) and for 3 ragged 1D objects ---
+    X = rng.uniform(0., 10., (20, 2))
+    e = np.full(20, 0.15)
+    hyp2 = np.array([1.0, 2.5, 2.0, 0.8])
+    with quiet():
+        Kt = ref.rbf_kernel_2d(X, hyp2, y_err=e)
+        yv = np.linalg.cholesky(Kt) @ rng.standard_normal(20)
+        bp = ref.build_pull([yv], [X], hyp2, nugget=0.02, y_err=[e], kernel='RBF2D')
+        bp.compute_pull(svd_method=False)
+    save('pull_2d_n20', x=X, y=yv, e=e, hyp=hyp2, nugget=0.02, pull=np.array(bp.pull), residual=np.array(bp.residual),
+         pull_average=bp.pull_average, pull_std=bp.pull_std)
+    ns = (14, 23, 9)
+    xs = [np.sort(rng.uniform(0., 6., k)) for k in ns]
+    es = [rng.uniform(0.1, 0.25, k) for k in ns]
+    ys = [smooth_1d(rng, xi, 0.15) for xi in xs]
+    b3 = ref.build_pull(ys, xs, np.array([0.9, 1.2]), nugget=0.01, y_err=es)
+    b3.compute_pull(svd_method=False)
+    b3s = ref.build_pull(ys, xs, np.array([0.9, 1.2]), nugget=0.01, y_err=es)
+    b3s.compute_pull(svd_method=False, diff=[0.1, -0.2, 0.05])
+    pack = {}
+    for i in range(3):
+        pack['x_%d' % i], pack['y_%d' % i], pack['e_%d' % i] = xs[i], ys[i], es[i]
+    save('pull_nobject_1d', nobj=3, hyp=np.array([0.9, 1.2]), nugget=0.01, pull=np.array(b3.pull),
+         residual=np.array(b3.residual), pull_average=b3.pull_average, pull_std=b3.pull_std,
+         diff=np.array([0.1, -0.2, 0.05]), pull_diff=np.array(b3s.pull), residual_diff=np.array(b3s.residual), **pack)
+
+    # ---------------- a5 on a noise-free matrix: svd_method=True prediction, dropped modes ----------------
+    # sigma = 0.05 puts the largest singular value at ~0.07, so the reference's 1e-15 threshold sits ~1e-14 below it in relative
+    # terms, two orders above the rounding noise of the decomposition (~1e-17): which modes pass is a property of the matrix,
+    # not of LAPACK's noise (checked below: no singular value within a factor 3 of the threshold)
+    x = np.linspace(0., 5., 40)
+    hyp = np.array([0.05, 1.0])
+    K = ref.rbf_kernel_1d(x, hyp)
+    sv = np.linalg.svd(K, compute_uv=False)
+    assert np.min(np.abs(np.log10(sv) + 15.)) > np.log10(3.), sv
+    w = np.exp(-0.5 * (x - 2.2) ** 2) - 0.6 * np.exp(-0.5 * ((x - 3.6) / 0.7) ** 2)
+    y = 0.05 * w                                   # a smooth function of the kernel's own scale
+    xn = np.linspace(0.1, 4.9, 17)
+    gs = ref.gaussian_process(y, x, kernel='RBF1D')
+    gs.hyperparameters = hyp
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gs.get_prediction(new_binning=xn, svd_method=True)
+        inv, logdet = ref.svd_inverse(K, return_logdet=True)
+    save('svd_noise_free_n40', x=x, y=y, xnew=xn, hyp=hyp, singular_values=sv, kept=int(np.sum(sv > 1e-15)),
+         dropped=int(np.sum(sv <= 1e-15)), pred=gs.Prediction[0].copy(), cov_diag=np.diag(gs.covariance_matrix[0]).copy(),
+         logdet=float(logdet), printed=np.array(buf.getvalue()))
+
+
 if __name__ == '__main__':
-    main()
+    if '--round3' in sys.argv:
+        main_round3()
+    else:
+        main()

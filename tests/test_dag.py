@@ -322,3 +322,34 @@ def test_dag_give_up_is_reported_on_first_and_replayed_calls(monkeypatch):
     ll2, info = dev.sweep_loglik(kps, dg)
     dev.close()
     assert np.isfinite(ll) and info[0] == 0 and abs(ll2[0] - ll) <= 1e-11 * abs(ll)
+
+
+def _tool(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', name + '.py')
+    spec = importlib.util.spec_from_file_location('cgp_tool_' + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_dag_randomised_stress_subset(monkeypatch):
+    """A seeded ~12-s pass of tools/dag_stress.py: random sizes / batch sizes / prediction grids / grids of 3, 9, 40 and all
+    workgroups / objects per launch, every entry point that takes the single-launch route (fit, gradient, batched fit,
+    leave-one-out), each result against the launch-per-step route.  (The full 150-s run of round 2 -- 3287 cases -- stays a
+    tool; this subset is what a compiler bump must keep green.)"""
+    for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_MIN_NB', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_NO_GRAPH'):
+        monkeypatch.delenv(k, raising=False)
+    cases, bad, worst = _tool('dag_stress').run_stress(12., seed=20263, sizes=(130, 257, 400, 640, 900, 1300, 2050, 2600), verbose=True)
+    assert cases >= 20 and bad == 0, (cases, bad, worst)
+
+
+def test_dag_concurrent_launches_subset(monkeypatch):
+    """Four host threads, four handles, ~6 s: persistent launches of different streams compete for the CUs (a launch may run with
+    only part of its workgroups resident), every result bit-identical to the same call done alone, and no bounded spin gives
+    up (tools/dag_concurrent_stress.py)."""
+    for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_BMAX', 'CGP_NO_GRAPH', 'CGP_DAG_TIMEOUT_MS'):
+        monkeypatch.delenv(k, raising=False)
+    count, bad, errors = _tool('dag_concurrent_stress').run_concurrent(6., 4, sizes=(2600, 1300, 900, 2050))
+    assert not errors and not any(bad) and min(count) >= 3, (count, bad, errors)

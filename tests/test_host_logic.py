@@ -179,3 +179,42 @@ def test_bench_file_fallback_communicator(tmp_path):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+
+
+def test_bench_launch_ranks_end_to_end(tmp_path, capfd):
+    """bench.py --gpus N run plainly starts its ranks itself (bench.launch_ranks): rank 0's single JSON line is passed through
+    and the exit code is 0 when every rank succeeds; a rank that dies takes the others down (they would wait for it inside a
+    collective for ever) and the launcher exits non-zero.  Driven here with stand-in ranks that only use the file
+    communicator (CGP_BENCH_COMM=file is the only way bench.py itself ever uses it), three processes, no GPU."""
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'rank.py'
+    script.write_text(textwrap.dedent('''
+        import json, os, sys, time, numpy as np
+        sys.path.insert(0, %r)
+        import bench
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["CGP_BENCH_CHILD"] == "1" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        c = bench.FileComm(r, w)
+        c.barrier()
+        if sys.argv[1] == "die" and r == 1:
+            sys.exit(7)
+        if sys.argv[1] == "die":
+            time.sleep(60)                      # the survivors "hang in the collective": the launcher must end them
+        worst = c.allreduce_max(float(r))
+        if r == 0:
+            print(json.dumps(dict(metric="gp_fits_per_sec", n_gpus=w, worst=worst)))
+        c.close()
+    ''' % root))
+    sys.path.insert(0, root)
+    import bench
+    import json
+    import time
+    rc = bench.launch_ranks(3, script=str(script), argv=['ok'])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1 and json.loads(out[0]) == dict(metric='gp_fits_per_sec', n_gpus=3, worst=2.0)
+    t0 = time.time()
+    rc = bench.launch_ranks(3, script=str(script), argv=['die'])
+    out = capfd.readouterr().out.strip()
+    assert rc != 0 and out == '' and time.time() - t0 < 40

@@ -308,3 +308,63 @@ def test_gp_2d_with_mean_function(cg):
     y0, new_y0 = f(X) + diff, f(Xn) + diff
     ref = orc.predict([y - y0], [X], 'RBF2D', [0.4, 1.5, 1.5, 0.], 0., [e], new_binning=Xn, svd_method=False)
     np.testing.assert_allclose(gp.Prediction[0], ref['prediction'][0] + new_y0, rtol=0, atol=1e-9)
+
+
+# ----------------------------------------------------------------- round 3: goldens the reference could still give
+def test_find_hyperparameters_2d_golden():
+    """2D fit against the reference (the notebooks fit in 2D).  sigma is not compared: the reference's 2D train-train matrix
+    carries no sigma^2 (kernel.py:146), the likelihood is flat in it and Nelder-Mead's walk along it is rounding noise."""
+    import cosmogp_amd
+    from conftest import load_golden
+    g = load_golden('fit_2d_n100')
+    gp = cosmogp_amd.gaussian_process_2d(g['y'], g['x'], y_err=g['e'])
+    gp.find_hyperparameters(hyperparameter_guess=np.array(g['guess']), svd_method=False)
+    np.testing.assert_allclose(gp.hyperparameters[1:], g['fit_hyp'][1:], rtol=1e-3)
+    gp.compute_log_likelihood(gp.hyperparameters, svd_method=False)
+    assert abs(gp.log_likelihood[0] - float(g['loglik_at_fit'])) <= 1e-6 * abs(float(g['loglik_at_fit']))
+    gp.compute_log_likelihood(g['guess'], svd_method=False)
+    assert abs(gp.log_likelihood[0] - float(g['loglik_at_guess'])) <= 1e-11 * abs(float(g['loglik_at_guess']))
+
+
+def test_pull_2d_and_ragged_objects_golden():
+    import cosmogp_amd
+    from conftest import load_golden
+    g = load_golden('pull_2d_n20')
+    bp = cosmogp_amd.build_pull([g['y']], [g['x']], g['hyp'], nugget=float(g['nugget']), y_err=[g['e']], kernel='RBF2D')
+    bp.compute_pull(svd_method=False)
+    np.testing.assert_allclose(bp.pull, g['pull'], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(bp.residual, g['residual'], rtol=0, atol=1e-8)
+    assert abs(bp.pull_average - float(g['pull_average'])) < 1e-8 and abs(bp.pull_std - float(g['pull_std'])) < 1e-8
+    g = load_golden('pull_nobject_1d')
+    n = int(g['nobj'])
+    xs, ys, es = ([g['%s_%d' % (k, i)] for i in range(n)] for k in 'xye')
+    b3 = cosmogp_amd.build_pull(ys, xs, g['hyp'], nugget=float(g['nugget']), y_err=es)
+    b3.compute_pull(svd_method=False)
+    np.testing.assert_allclose(b3.pull, g['pull'], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(b3.residual, g['residual'], rtol=0, atol=1e-8)
+    assert abs(b3.pull_std - float(g['pull_std'])) < 1e-8
+    bd = cosmogp_amd.build_pull(ys, xs, g['hyp'], nugget=float(g['nugget']), y_err=es)
+    bd.compute_pull(svd_method=False, diff=list(g['diff']))
+    np.testing.assert_allclose(bd.pull, g['pull_diff'], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(bd.residual, g['residual_diff'], rtol=0, atol=1e-8)
+
+
+def test_svd_route_noise_free_golden():
+    """The reference's default route (svd_method=True) on noise-free data: K is numerically singular, the eigensolver route
+    must keep / drop the same modes as the reference (its spectrum crosses the 1e-15 threshold two orders above any
+    decomposition's rounding noise, so the split is a property of the matrix) and give the same prediction.  Tolerances: the
+    kept modes reach down to 1e-15, K^+ has entries ~1e14; the prediction H K^+ y and the variance K** - H K^+ H^T are stable
+    to ~1e-7 relative of sigma^2 = 2.5e-3 (the reference's own values carry that noise: its variances come out at -1e-7)."""
+    import cosmogp_amd
+    from conftest import load_golden
+    g = load_golden('svd_noise_free_n40')
+    dev = cosmogp_amd.default_device()
+    K = cosmogp_amd.rbf_kernel_1d(g['x'], g['hyp'])
+    inv, ld, ndrop = dev.svd_inverse(K, thresh=1e-15)
+    assert ndrop == int(g['dropped'])
+    assert abs(ld - float(g['logdet'])) <= 1e-6 * abs(float(g['logdet']))
+    gp = cosmogp_amd.gaussian_process(g['y'], g['x'], kernel='RBF1D')
+    gp.hyperparameters = np.array(g['hyp'])
+    gp.get_prediction(new_binning=g['xnew'], svd_method=True)
+    np.testing.assert_allclose(gp.Prediction[0], g['pred'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(gp.variance[0], g['cov_diag'], rtol=0, atol=1e-6)
