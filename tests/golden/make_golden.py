@@ -367,16 +367,19 @@ def main_round3():
          diff=np.array([0.1, -0.2, 0.05]), pull_diff=np.array(b3s.pull), residual_diff=np.array(b3s.residual), **pack)
 
     # ---------------- a5 on a noise-free matrix: svd_method=True prediction, dropped modes ----------------
-    # sigma = 0.05 puts the largest singular value at ~0.07, so the reference's 1e-15 threshold sits ~1e-14 below it in relative
-    # terms, two orders above the rounding noise of the decomposition (~1e-17): which modes pass is a property of the matrix,
-    # not of LAPACK's noise (checked below: no singular value within a factor 3 of the threshold)
+    # sigma = 0.0043 puts the largest singular value at 3.2e-4, so the reference's ABSOLUTE 1e-15 threshold sits at 3e-12 of it:
+    # four orders above the rounding noise of LAPACK's decomposition and 60 x above that of the device's two-sided Jacobi
+    # (~200 eps |K|: with sigma = 0.05 the same spectrum puts a 3.0e-15 mode next to the threshold and the two
+    # decompositions split it differently).  Which modes pass is then a property of the matrix (checked below: no singular
+    # value within a factor 3 of the threshold, and the threshold above 1000 eps |K|)
     x = np.linspace(0., 5., 40)
-    hyp = np.array([0.05, 1.0])
+    hyp = np.array([0.0043, 1.0])
     K = ref.rbf_kernel_1d(x, hyp)
     sv = np.linalg.svd(K, compute_uv=False)
     assert np.min(np.abs(np.log10(sv) + 15.)) > np.log10(3.), sv
+    assert 1e-15 > 1000. * np.finfo(float).eps * sv[0]
     w = np.exp(-0.5 * (x - 2.2) ** 2) - 0.6 * np.exp(-0.5 * ((x - 3.6) / 0.7) ** 2)
-    y = 0.05 * w                                   # a smooth function of the kernel's own scale
+    y = hyp[0] * w                                 # a smooth function of the kernel's own scale
     xn = np.linspace(0.1, 4.9, 17)
     gs = ref.gaussian_process(y, x, kernel='RBF1D')
     gs.hyperparameters = hyp
