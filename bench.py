@@ -487,7 +487,7 @@ def main():
                 print('rank %d: RCCL reports %d ranks, launched with %d' % (rank, rccl_ranks, world), file=sys.stderr)
                 sys.exit(3)
             collective = 'RCCL inside the library (cgp_comm_*: ncclAllGather / ncclAllReduce on the handle\'s stream)'
-    wl = make_workload(args.workload, rank)
+    wl = make_workload(args.workload, rank, nobj=int(os.environ.get('CGP_BENCH_C4_NOBJ', '128')))
     batched = 'B' in wl
     # Batches of objects with >= 16 tile columns (N >= 2048) are factored by ONE persistent launch per group of objects
     # (csrc/dag.hpp, several leaf lanes + one interleaved task list); smaller objects and CGP_NO_DAG_BATCH=1 take one launch

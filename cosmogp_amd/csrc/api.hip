@@ -46,6 +46,11 @@ constexpr long CGP_MAX_SWEEP = 256;     // candidates per cgp_sweep_loglik call
 constexpr size_t LEAF_LDS = (size_t)(CGP_NB * CGP_LDA + 8 * 256 + 144) * sizeof(double);
 
 inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
+// Tall rows (the new points' cross rows + the residual row) of a fit with m new points: padded to a whole 128-row tile for
+// objects large enough for the single-launch factorisation (its tiles are 128 x 128), to 64 rows for the small ones, whose
+// launch-per-step kernels work in units of 64 rows: a light curve of N = 512 predicted at M = 19 points then carries 64
+// tall rows instead of 128 through every solve and update (21 % of the flops of its sweep, 10 % of its time).
+inline long tall_rows(long m, long Np) { return round_up(m + 1, Np >= 2048 ? 128 : 64); }
 
 struct DevBuf {
     void* p = nullptr;
@@ -417,7 +422,7 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     // The 128 x 64 form pays from ~1024 tiles per launch on, but only on updates of large objects (the route of the small
     // ones since the single launch took over the large: batches of <= 1920-point objects are 2-6 % faster on the 64 x 64 form
     // whatever the tile count, tools/batch_time.py with CGP_BIGTILE).  Both forms sum in the same order: same bits.
-    const bool big_form = bulk_cap == 0 &&
+    const bool big_form = bulk_cap == 0 && rows % 128 == 0 &&
         tiles_big_ * B >= h->env.bigtile && (rows >= 2048 || cols >= 2048);
     StageScope sc(h, big_form ? ST_GEMM_BIG : ST_GEMM);
     h->gemm_launches++;
@@ -1205,7 +1210,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_fit: no data (call cgp_fit_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu))) return fail(h, CGP_E_ARG, "cgp_fit: bad argument");
     Prob& P = h->P;
-    const long Mp = round_up(m + 1, NB);
+    const long Mp = tall_rows(m, P.Np);
     CHK(bind_single(h, Mp, false));
     CHK(upload_kp(h, kp, kss_noise));
     remember_fit_kp(h, kp, kss_noise);
@@ -1244,7 +1249,7 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     if (!h->factored) return fail(h, CGP_E_STATE, "cgp_fit_predict: no factor (call cgp_fit first)");
     if (!xnew || m <= 0 || !mu) return fail(h, CGP_E_ARG, "cgp_fit_predict: bad argument");
     Prob& P = h->P;
-    const long Mp = round_up(m + 1, NB);
+    const long Mp = tall_rows(m, P.Np);
     CHK(bind_single(h, Mp, true));
     const long ld = P.Np;
     CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
@@ -1265,19 +1270,22 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     CHK(d2h(h, mu, P.mu, m * sizeof(double)));
     if (var) CHK(d2h(h, var, P.var, m * sizeof(double)));
     if (cov) {
-        // K(new,new; nugget) - W W^T, full matrix   [Gaussian_process.py:356-361]
-        CHK(ensure(h, h->bC, (size_t)Mp * Mp * sizeof(double)));
-        CHK(ensure(h, h->bdiag2, Mp * sizeof(double)));
+        // K(new,new; nugget) - W W^T, full matrix   [Gaussian_process.py:356-361].  The assembly works on 128-column tiles:
+        // the square is laid out with a leading dimension rounded up to 128, the product covers its first Mp rows / columns
+        const long Mc = round_up(Mp, NB);
+        CHK(ensure(h, h->bC, (size_t)Mc * Mc * sizeof(double)));
+        CHK(ensure(h, h->bdiag2, Mc * sizeof(double)));
         CHK(ensure(h, h->bns2, sizeof(int)));
         CHK(ensure(h, h->bout, (size_t)m * m * sizeof(double)));
+        CHK(upload_padded(h, h->boxn, xnew, (size_t)m * P.dim, (size_t)Mc * P.dim));     // the grid again, padded to Mc points
         int mi = (int)m;
         CHK(h2d(h, h->bns2.p, &mi, sizeof(int)));
-        hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mp, kss_noise);
-        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, Mp, 0, P.xnew, 0, (double*)h->bdiag2.p, 0,
-                                  (int*)h->bns2.p, Mp, false, false));
-        CHK(launch_gemm(h, 1, (double*)h->bC.p, Mp, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, Mp, Mp, P.Np, false,
+        hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, h->stream, (double*)h->bdiag2.p, Mc, kss_noise);
+        CHK(launch_assemble_train(h, P.dim, 1, (double*)h->bC.p, Mc, 0, (const double*)h->boxn.p, 0, (double*)h->bdiag2.p, 0,
+                                  (int*)h->bns2.p, Mc, false, false));
+        CHK(launch_gemm(h, 1, (double*)h->bC.p, Mc, 0, P.M + P.Np * ld, P.M + P.Np * ld, ld, 0, Mp, Mp, P.Np, false,
                         -1.0, 1.0));
-        hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->bC.p, Mp,
+        hipLaunchKernelGGL(k_extract_square, dim3(256), dim3(256), 0, h->stream, (const double*)h->bC.p, Mc,
                            (double*)h->bout.p, (int)m, 0);
         HIPCHK(hipGetLastError());
         CHK(d2h(h, cov, h->bout.p, (size_t)m * m * sizeof(double)));
@@ -1477,7 +1485,7 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     double* V = (double*)h->jV.p;
     JacStat* st = (JacStat*)h->jstat.p;
     // (jVD is free until k_jac_finish: its head holds the partial sums of the norm)
-    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)K, ld, (int)Np, (double*)h->jVD.p);
+    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)K, ld, (int)Np, (int)n, (double*)h->jVD.p);
     hipLaunchKernelGGL(k_jac_norm, dim3(1), dim3(1024), 0, h->stream, (const double*)h->jVD.p, h->env.jac_tol, st);
     hipLaunchKernelGGL(k_jac_identity, dim3(512), dim3(256), 0, h->stream, V, ld, (int)Np);
     HIPCHK(hipGetLastError());
@@ -1789,7 +1797,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit: no resident batch (call cgp_batch_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
         return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
-    const long Mp = round_up(m + 1, NB);
+    const long Mp = tall_rows(m, Q.Np);
     Q.R = Q.Np + Mp;
     Q.sM = Q.R * Q.Np;
     Q.kps = 0;                                  // one shared parameter set (a sweep may have left 1)

@@ -56,6 +56,9 @@ struct DagParams {
 };
 
 #define DAG_THREADS 512
+#ifndef DAG_UPD_KS
+#define DAG_UPD_KS 20
+#endif
 #define DAG_LDS_DOUBLES (CGP_NB * CGP_LDA + 8 * 256 + 160)
 #define DAG_LDS_BYTES (DAG_LDS_DOUBLES * 8 + 128)      // + control words
 
@@ -179,9 +182,22 @@ __device__ __noinline__ int dag_fetch(unsigned* ctrl, const int4* tasks, int nta
 // Column slot (J, lp) of a wave's 32 columns stands for column 8 (J >> 1) + 2 lp + (J & 1): a lane's values for J, J + 1 are
 // two adjacent doubles, so the read-modify-write of C moves 16 bytes per lane and 64 contiguous bytes per row.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef DAG_UPD_STAMPS
+__device__ unsigned long long g_upd_acc[8];        // tools/dag_probe.hip: time of one update task by phase (100 MHz ticks), workgroup 1
+#define DAG_UPD_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 1) st_[i] = wall_clock64(); } while (0)
+#else
+#define DAG_UPD_STAMP(i) do {} while (0)
+#endif
 __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const double* Bg, long ld, int K) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int TM = 128, TN = 128, WN = 4, KB = 16, KS = KB + 2, CPR = KB / 2;
+#ifdef DAG_UPD_STAMPS
+    long long st_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    DAG_UPD_STAMP(0);
+    // KS = 20 doubles = 10 sixteen-byte slots per row: the four 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS) then
+    // hit 16 different slots both for the A fragments (rows lr, slot 10 lr + lq) and for the B fragments (4 lp + lq); with
+    // KS = 18 the A reads were 2-way conflicts (SQ_LDS_BANK_CONFLICT = 20 % of the LDS cycles of round 2's kernel)
+    constexpr int TM = 128, TN = 128, WN = 4, KB = 16, KS = DAG_UPD_KS, CPR = KB / 2;
     constexpr int MT = 4, NJ = 8, PA = 2, PB = 2, RSTEP = DAG_THREADS / CPR;      // 64 rows per staging pass
     double* As = smem;                      // [2][TM * KS]
     double* Bs = smem + 2 * TM * KS;        // [2][TN * KS]
@@ -280,6 +296,7 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
     __builtin_amdgcn_sched_barrier(0);
     lstore(P0{}, 0);
     __syncthreads();
+    DAG_UPD_STAMP(1);
     fread(P0{}, 0, 0);
     for (int kt = 0; kt < nk; kt += 2) {
         // stage in buffer 0; stage kt + 1 goes to buffer 1 meanwhile
@@ -307,6 +324,7 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
         fmma(P1{});
         interleave_reads();
     }
+    DAG_UPD_STAMP(2);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -316,6 +334,15 @@ __device__ __forceinline__ void dag_upd_tile(double* Cg, const double* Ag, const
             o.y = -acc[i][2 * jj + 1];
             stc2(rc_, coff + (unsigned)(16 * i) * ldb + (unsigned)(8 * jj) * 8u, o);
         }
+#ifdef DAG_UPD_STAMPS
+    DAG_UPD_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DAG_UPD_STAMP(4);
+    if (threadIdx.x == 0 && blockIdx.x == 1) {
+        g_upd_acc[0] += st_[1] - st_[0]; g_upd_acc[1] += st_[2] - st_[1]; g_upd_acc[2] += st_[3] - st_[2]; g_upd_acc[3] += st_[4] - st_[3];
+        g_upd_acc[4] += 1;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

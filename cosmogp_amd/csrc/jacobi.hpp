@@ -35,15 +35,18 @@ struct JacStat {
 // ||K||_F and the threshold in two launches: per-workgroup partial sums of squares in a fixed order (the result does not
 // depend on the grid's scheduling), then one workgroup adds the partials
 #define JAC_NORM_BLOCKS 1024
-__global__ __launch_bounds__(256) void k_jac_norm_partial(const double* __restrict__ K, long ld, int Np, double* __restrict__ part) {
+// (only the n x n matrix proper: the identity padding up to Np must not enter the norm -- for a matrix of small scale, e.g.
+// sigma^2 = 2e-5, the padding's ones would set the threshold, and rotations the size of the matrix's own small eigenvalues
+// would be skipped: the round-3 noise-free golden came out with one kept mode missing until this was fixed)
+__global__ __launch_bounds__(256) void k_jac_norm_partial(const double* __restrict__ K, long ld, int Np, int n, double* __restrict__ part) {
     __shared__ double red[4];
     double s = 0.;
-    const long half = Np / 2, tot = (long)Np * half;
+    const long half = Np / 2, tot = (long)n * half;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long)JAC_NORM_BLOCKS * 256) {
         const long r = idx / half, c = (idx - r * half) * 2;
         const double2 v = *(const double2*)(K + r * ld + c);
-        s = fma(v.x, v.x, s);
-        s = fma(v.y, v.y, s);
+        if (c < n) s = fma(v.x, v.x, s);
+        if (c + 1 < n) s = fma(v.y, v.y, s);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);

@@ -368,10 +368,9 @@ def main_round3():
 
     # ---------------- a5 on a noise-free matrix: svd_method=True prediction, dropped modes ----------------
     # sigma = 0.0043 puts the largest singular value at 3.2e-4, so the reference's ABSOLUTE 1e-15 threshold sits at 3e-12 of it:
-    # four orders above the rounding noise of LAPACK's decomposition and 60 x above that of the device's two-sided Jacobi
-    # (~200 eps |K|: with sigma = 0.05 the same spectrum puts a 3.0e-15 mode next to the threshold and the two
-    # decompositions split it differently).  Which modes pass is then a property of the matrix (checked below: no singular
-    # value within a factor 3 of the threshold, and the threshold above 1000 eps |K|)
+    # four orders above the rounding noise of LAPACK's decomposition (and of a correct Jacobi eigensolver).  Which modes pass
+    # is then a property of the matrix (checked below: no singular value within a factor 3 of the threshold, and the
+    # threshold above 1000 eps |K|)
     x = np.linspace(0., 5., 40)
     hyp = np.array([0.0043, 1.0])
     K = ref.rbf_kernel_1d(x, hyp)

@@ -351,12 +351,14 @@ def test_pull_2d_and_ragged_objects_golden():
 
 def test_svd_route_noise_free_golden():
     """The reference's default route (svd_method=True) on noise-free data: K is numerically singular, the eigensolver route
-    must keep / drop the same modes as the reference and give the same prediction.  The fixture puts the reference's ABSOLUTE
-    1e-15 threshold in a gap of the spectrum (3.5e-15 kept, 2.9e-16 dropped) at 3e-12 of the largest singular value: 60 x above
-    the eigenvalue noise of the device's two-sided Jacobi (~200 eps |K|, measured: with sigma = 0.05 the same spectrum has
-    a 3.0e-15 mode that the device computes below 1e-15 and drops -- 22 dropped against the reference's 21 -- so THAT case
-    is unpinnable).  Tolerances: kept modes reach down to 1e-11 |K|, so the prediction H K^+ y is compared at
-    1e-6 sigma and the variance K** - H K^+ H^T at 1e-6 sigma^2 (its golden values, ~1e-7 sigma^2, are themselves rounding)."""
+    must keep / drop the same modes as the reference (inv_matrix.py:7-9 prints the dropped count) and give the same
+    prediction.  The fixture puts the reference's ABSOLUTE 1e-15 threshold in a gap of the spectrum (3.5e-15 kept, 2.9e-16
+    dropped) at 3e-12 of the largest singular value, far above the rounding noise of either decomposition, so the split is a
+    property of the matrix.  (This fixture found a bug: the rotation threshold of the device's Jacobi sweeps was eps times the
+    Frobenius norm of the identity-PADDED matrix, i.e. ~2e-15 for any small-scale matrix, and the 3.5e-15 mode came out below
+    1e-15; the norm now covers the n x n matrix proper.)  Tolerances: kept modes reach down to 1e-11 |K|, so the prediction
+    H K^+ y is compared at 1e-6 sigma and the variance K** - H K^+ H^T at 1e-6 sigma^2 (its golden values, ~1e-7 sigma^2,
+    are themselves rounding)."""
     import cosmogp_amd
     from conftest import load_golden
     g = load_golden('svd_noise_free_n40')

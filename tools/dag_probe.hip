@@ -85,6 +85,11 @@ int main(int argc, char** argv) {
             ++nw; for (int cc = 0; cc < 4; ++cc) w[cc] += q[cc] * (cc < 3 ? 0.01 : 1.);
         }
         const double per = w[2] / w[3], unit = 2.0 * 128 * 128 * 128 * depth;
+#ifdef DAG_UPD_STAMPS
+        { unsigned long long a[8]; CK(hipMemcpyFromSymbol(a, HIP_SYMBOL(g_upd_acc), sizeof(a)));
+          if (a[4]) printf("update task of workgroup 1 (us): loads until the first stage is in LDS %.2f, K loop %.2f, negate + issue stores %.2f, drain of the stores %.2f (%llu tasks)\n",
+                           a[0] * 0.01 / a[4], a[1] * 0.01 / a[4], a[2] * 0.01 / a[4], a[3] * 0.01 / a[4], a[4]); }
+#endif
         printf("updbench depth %d: %zu tasks, %d workers: fetch+wait %.2f us/task, body+publish %.2f us/task -> %.1f GF/s per CU, %.1f TF/s on %d CUs (host wall %.2f ms)\n",
                depth, t.size(), nw, w[0] / w[3], per, unit / per * 1e-3, unit / (per + w[0] / w[3]) * 1e-6 * nw, nw, wall_ms);
         return 0;
