@@ -292,12 +292,22 @@ class Device(object):
 
     # ---- batched -------------------------------------------------------------------
     def batch_set_data(self, dim, xs, resids, diags=None):
-        """Upload B objects (lists of per-object arrays, ragged allowed) and keep them resident."""
+        """Upload B objects and keep them resident: lists of per-object arrays (ragged allowed), or -- objects of equal
+        length -- one C-contiguous (B, n[, 2]) / (B, n) / (B, n) array per quantity, which goes down without any per-object
+        work on the host."""
         B = len(xs)
-        ns = np.array([len(r) for r in resids], dtype=np.int64)
-        x = _f64(np.concatenate([np.asarray(a, dtype=np.float64).reshape(len(a), -1) for a in xs]).ravel())
-        r = _f64(np.concatenate(resids))
-        d = None if diags is None else _f64(np.concatenate(diags))
+        packed = (isinstance(xs, np.ndarray) and isinstance(resids, np.ndarray) and resids.ndim == 2 and xs.shape[:2] == resids.shape
+                  and (diags is None or (isinstance(diags, np.ndarray) and diags.shape == resids.shape)))
+        if packed:
+            # ONE (B, n[, 2]) array per quantity (objects of equal length): no per-object work on the host at all
+            ns = np.full(B, resids.shape[1], dtype=np.int64)
+            x, r = _f64(xs).ravel(), _f64(resids).ravel()
+            d = None if diags is None else _f64(diags).ravel()
+        else:
+            ns = np.array([len(r) for r in resids], dtype=np.int64)
+            x = _f64(np.concatenate([np.asarray(a, dtype=np.float64).reshape(len(a), -1) for a in xs]).ravel())
+            r = _f64(np.concatenate(resids))
+            d = None if diags is None else _f64(np.concatenate(diags))
         self.batch_generation += 1
         st = self._lib.cgp_batch_set_data(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
                                           _ptr(d))

@@ -1759,27 +1759,49 @@ int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, con
     Q.B = (int)B; Q.dim = dim; Q.n = nmax;
     Q.Np = round_up(nmax, NB);
     const long Np = Q.Np;
-    // pack ragged host arrays into padded [B][Np] layouts
-    std::vector<double> hx((size_t)B * Np * dim, 0.), hr((size_t)B * Np, 0.), hd((size_t)B * Np, 0.);
-    std::vector<int> hn(B);
-    long off = 0;
-    for (long b = 0; b < B; ++b) {
-        const long nb = ns[b];
-        hn[b] = (int)nb;
-        std::memcpy(&hx[(size_t)b * Np * dim], x + off * dim, nb * dim * sizeof(double));
-        std::memcpy(&hr[(size_t)b * Np], resid + off, nb * sizeof(double));
-        if (diag) std::memcpy(&hd[(size_t)b * Np], diag + off, nb * sizeof(double));
-        off += nb;
-    }
-    CHK(ensure(h, h->qx, hx.size() * sizeof(double)));
-    CHK(ensure(h, h->qr, hr.size() * sizeof(double)));
-    CHK(ensure(h, h->qdiag, hd.size() * sizeof(double)));
+    // ragged host arrays -> padded [B][Np] layouts, packed STRAIGHT into the pinned staging of the transfer (one copy on the
+    // host, not two); objects that fill their padded length (n = Np, e.g. the 512-point light curves of config 4) are one
+    // contiguous block per quantity
+    CHK(ensure(h, h->qx, (size_t)B * Np * dim * sizeof(double)));
+    CHK(ensure(h, h->qr, (size_t)B * Np * sizeof(double)));
+    CHK(ensure(h, h->qdiag, (size_t)B * Np * sizeof(double)));
     CHK(ensure(h, h->qns, B * sizeof(int)));
-    CHK(h2d(h, h->qx.p, hx.data(), hx.size() * sizeof(double)));
-    CHK(h2d(h, h->qr.p, hr.data(), hr.size() * sizeof(double)));
-    CHK(h2d(h, h->qdiag.p, hd.data(), hd.size() * sizeof(double)));
-    CHK(h2d(h, h->qns.p, hn.data(), B * sizeof(int)));
-    HIPCHK(stream_sync(h));       // host staging vectors die here
+    bool full = true;
+    for (long b = 0; b < B; ++b) full = full && ns[b] == Np;
+    auto put = [&](void* dst, const double* src, long width) -> int {          // width doubles per point
+        const size_t bytes = (size_t)B * Np * width * sizeof(double);
+        if (!src) { HIPCHK(hipMemsetAsync(dst, 0, bytes, h->stream)); return 0; }
+        if (full && bytes > PIN_MAX) {              // large and already in device layout: straight from the caller's array
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+            return 0;
+        }
+        std::vector<double> big;
+        double* st = bytes <= PIN_MAX ? (double*)pin_alloc(h, bytes) : nullptr;
+        if (!st) { big.resize(bytes / sizeof(double)); st = big.data(); }
+        if (full) std::memcpy(st, src, bytes);
+        else {
+            long off = 0;
+            for (long b = 0; b < B; ++b) {
+                double* row = st + (size_t)b * Np * width;
+                std::memcpy(row, src + off * width, (size_t)ns[b] * width * sizeof(double));
+                std::memset(row + ns[b] * width, 0, (size_t)(Np - ns[b]) * width * sizeof(double));
+                off += ns[b];
+            }
+        }
+        HIPCHK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, h->stream));
+        if (!big.empty()) HIPCHK(stream_sync(h));       // (pageable source: the copy has completed when the runtime returns)
+        return 0;
+    };
+    CHK(put(h->qx.p, x, dim));
+    CHK(put(h->qr.p, resid, 1));
+    CHK(put(h->qdiag.p, diag, 1));
+    {
+        int* hn = (int*)pin_alloc(h, B * sizeof(int));
+        if (!hn) return fail(h, CGP_E_HIP, "cgp_batch_set_data: no pinned staging");
+        for (long b = 0; b < B; ++b) hn[b] = (int)ns[b];
+        HIPCHK(hipMemcpyAsync(h->qns.p, hn, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(stream_sync(h));       // the staging chunks are recycled by the next call
     h->have_batch = true;
     return CGP_OK;
 }
