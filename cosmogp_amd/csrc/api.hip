@@ -564,14 +564,16 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             int w = 4;
             if (force) w = force;
             else if ((rows / 64) * P.B > cus) w = ((rows / 128) * P.B > cus && rows % 256 == 0) ? 16 : 8;
-            if (rows % (16 * w) != 0) w = 4;
-            const dim3 g((unsigned)(rows / (16 * w)), 1, P.B);
+            // (rows is a multiple of 64; with 8 waves the last workgroup of an odd number of 64-row groups is half full, which
+            // costs less than the twice as many 4-wave workgroups each staging L_kk for itself)
+            if (rows % 64 != 0 || (w == 16 && rows % 256 != 0)) w = 4;
+            const dim3 g((unsigned)((rows + 16 * w - 1) / (16 * w)), 1, P.B);
             if (w == 4)
-                hipLaunchKernelGGL(k_trsm_panel<4>, g, dim3(256), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+                hipLaunchKernelGGL(k_trsm_panel<4>, g, dim3(256), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
             else if (w == 8)
-                hipLaunchKernelGGL(k_trsm_panel<8>, g, dim3(512), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+                hipLaunchKernelGGL(k_trsm_panel<8>, g, dim3(512), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
             else
-                hipLaunchKernelGGL(k_trsm_panel<16>, g, dim3(1024), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk);
+                hipLaunchKernelGGL(k_trsm_panel<16>, g, dim3(1024), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
             HIPCHK(hipGetLastError());
         }
         return 0;                                // leaf kernels run on the main stream in order: no mark needed

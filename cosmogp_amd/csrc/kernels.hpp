@@ -527,7 +527,7 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
 template <int K4W>
 __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
-    long sW, int blk) {
+    long sW, int blk, int nrows) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ls = smem;                               // [128][CGP_LDA] strictly-lower tiles used
     double* Ws = smem + CGP_NB * CGP_LDA;            // [8][16][16]
@@ -542,16 +542,21 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     const int xg = wave < 6 ? 0 : (wave < 12 ? 1 : 2), xt = wave - 6 * xg;
     double* Xs = Ls + xg * 16 * CGP_LDA + (xg == 2 ? 32 : 16) + 18 * xt;
     double* Ap = M + (long)(r0 + blockIdx.x * (16 * K4W) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
+    // nrows need not fill the last workgroup (the tall rows of small objects come in units of 64): its surplus waves help
+    // to stage L_kk and then have no rows of their own
+    const bool has_rows = (int)(blockIdx.x * (16 * K4W) + wave * 16) < nrows;
 
     CGP_STAMP(50);
     // This wave's 16 x 128 panel rows in MFMA result layout.  The column slot (J, u) of a 16-wide
     // tile stands for column 4 u + J (any fixed permutation is legal as long as the B operands use
     // the same one), so a lane's four J values are 4 contiguous doubles: 16-byte loads/stores.
     double S[8][4];
+    if (has_rows) {
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        d2 t0 = *(const d2*)(Ap + jb * 16), t1 = *(const d2*)(Ap + jb * 16 + 2);
-        S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
+        for (int jb = 0; jb < 8; ++jb) {
+            d2 t0 = *(const d2*)(Ap + jb * 16), t1 = *(const d2*)(Ap + jb * 16 + 2);
+            S[jb][0] = t0.x; S[jb][1] = t0.y; S[jb][2] = t1.x; S[jb][3] = t1.y;
+        }
     }
     // L_kk -> LDS by direct global -> LDS loads (global_load_lds_dwordx4): one wave instruction moves one full
     // row of the block (64 lanes x 16 B = 128 doubles) to Ls[r][0..127], all rows of a wave in flight at once.
@@ -570,6 +575,7 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CGP_STAMP(51);
+    if (!has_rows) return;
 
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {

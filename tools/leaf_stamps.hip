@@ -21,7 +21,7 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         hipMemcpy(M, h.data(), h.size() * 8, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(CGP_K3_THREADS), lds, 0, M, ld, 0L, 0, ws, 0L, ldp, 0L, info, 0);
-        hipLaunchKernelGGL(k_trsm_panel<4>, dim3((R - 128) / 64), dim3(256), lds, 0, M, ld, 0L, 0, 128, ws, 0L, 0);
+        hipLaunchKernelGGL(k_trsm_panel<4>, dim3((R - 128) / 64), dim3(256), lds, 0, M, ld, 0L, 0, 128, ws, 0L, 0, (int)(R - 128));
         hipDeviceSynchronize();
     }
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
