@@ -195,10 +195,21 @@ class Gaussian_process(object):
         return bool(SVD_VIA_CHOLESKY_WHEN_PD)
 
     def _res_token(self, sn):
-        """Identity of object sn's data in HBM: the handle's data generation, the index and the ids of the
-        arrays it was uploaded from (REPLACING gp.y[sn] / gp.Time[sn] / gp.y_err[sn] by new arrays is
-        noticed; mutating them in place is not -- call invalidate() after that)."""
-        return (self.device.generation, sn, id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn]))
+        """Identity of object sn's data in HBM: the handle's data generation, the index, the ids of the arrays it was uploaded
+        from AND a fingerprint of their contents (length, sum, first / middle / last element of y, Time, y_err; y0 and diff):
+        replacing gp.y[sn] / gp.Time[sn] / gp.y_err[sn] by new arrays is noticed, and so is the usual in-place edit
+        (`gp.y_err[0] *= 2`, `gp.y[0][:] = ...`) -- the reference re-reads the arrays on every call
+        (Gaussian_process.py:207-211).  An edit that leaves all of these unchanged needs invalidate().  (One O(n) sum per array
+        and call: microseconds beside a fit.  The many-object batch token stays on identities: see _batch_upload.)"""
+        def fp(a):
+            a = np.asarray(a)
+            if a.size == 0:
+                return (0,)
+            f = a.reshape(-1)
+            return (f.size, float(f.sum()), float(f[0]), float(f[f.size // 2]), float(f[-1]))
+        y0 = self.y0[sn] if self.y0 is not None else 0.
+        return (self.device.generation, sn, id(self.y[sn]), id(self.Time[sn]), id(self.y_err[sn]),
+                fp(self.y[sn]), fp(self.Time[sn]), fp(self.y_err[sn]), fp(y0))
 
     def _make_resident(self, sn):
         """Upload object sn unless it already is the resident object of the handle; returns the diagonal

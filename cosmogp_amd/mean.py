@@ -21,17 +21,31 @@ def fit_mean_2d(old_binning, mean_function):
     is fitted from scratch (task=0, same defaults); LAST_BISPLREP_TASK says which one ran."""
     global LAST_BISPLREP_TASK
     old_binning = np.asarray(old_binning, dtype=np.float64)
+    mean_function = np.asarray(mean_function, dtype=np.float64)
+    # genuine argument errors are reported as such, never papered over by the second attempt
+    if old_binning.ndim != 2 or old_binning.shape[1] != 2 or mean_function.shape != (old_binning.shape[0],):
+        raise ValueError('the 2D mean needs coordinates of shape (n, 2) and n mean values, got %r and %r'
+                         % (old_binning.shape, mean_function.shape))
+    if not (np.all(np.isfinite(old_binning)) and np.all(np.isfinite(mean_function))):
+        raise ValueError('the 2D mean needs finite coordinates and values')
     try:
         tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=1)
         LAST_BISPLREP_TASK = 1
-    except (RuntimeError, ValueError, TypeError):
-        tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=0)
+    except (RuntimeError, ValueError, TypeError) as cold:
+        # only the cold-start failure of task=1 (no previous fit to continue) is answered by a fit from scratch; if that
+        # fails as well the FIRST error is the one the caller sees
+        try:
+            tck = inter.bisplrep(old_binning[:, 0], old_binning[:, 1], mean_function, task=0)
+        except (RuntimeError, ValueError, TypeError):
+            raise cold
         LAST_BISPLREP_TASK = 0
     return tck
 
 
 def interpolate_mean_2d(old_binning, mean_function, new_binning, device=None):
-    """Bivariate spline of the mean function on new points (cosmogp/mean.py:36-67): host fit, device evaluation."""
+    """Bivariate spline of the mean function on new points (cosmogp/mean.py:36-67): host fit, device evaluation.  Like
+    every product path of this package it needs the HIP library and a GPU: without them it raises _lib.HipUnavailable (there
+    is deliberately no host evaluation to fall back to)."""
     from . import _lib
     tck = fit_mean_2d(old_binning, mean_function)
     dev = device if device is not None else _lib.default_device()

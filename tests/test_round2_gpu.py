@@ -373,3 +373,39 @@ def test_svd_route_noise_free_golden():
     gp.get_prediction(new_binning=g['xnew'], svd_method=True)
     np.testing.assert_allclose(gp.Prediction[0], g['pred'], rtol=0, atol=1e-6 * sig)
     np.testing.assert_allclose(gp.variance[0], g['cov_diag'], rtol=0, atol=1e-6 * sig ** 2)
+
+
+def test_in_place_edits_of_the_data_are_noticed():
+    """The reference re-reads y / Time / y_err on every call (Gaussian_process.py:207-211); here an object stays resident in
+    HBM, so the residency token carries a fingerprint of the arrays' contents: the usual in-place edits must give the numbers
+    of a freshly built object (round-2 advisor finding)."""
+    import cosmogp_amd
+    rng = np.random.default_rng(12)
+    n = 300
+    x = np.sort(rng.uniform(0., 30., n))
+    e = rng.uniform(0.05, 0.1, n)
+    y = np.sin(x) + e * rng.standard_normal(n)
+    xn = np.linspace(0., 30., 25)
+
+    def fresh(y_, x_, e_):
+        g = cosmogp_amd.gaussian_process(y_.copy(), x_.copy(), kernel='RBF1D', y_err=e_.copy())
+        g.hyperparameters = np.array([0.8, 2.0])
+        g.get_prediction(new_binning=xn, svd_method=False)
+        g.compute_log_likelihood(g.hyperparameters, svd_method=False)
+        return g.Prediction[0].copy(), g.variance[0].copy(), float(g.log_likelihood[0])
+
+    gp = cosmogp_amd.gaussian_process(y.copy(), x.copy(), kernel='RBF1D', y_err=e.copy())
+    gp.hyperparameters = np.array([0.8, 2.0])
+    gp.get_prediction(new_binning=xn, svd_method=False)
+    p0 = gp.Prediction[0].copy()
+    gp.y_err[0] *= 2.                                   # in place
+    gp.get_prediction(new_binning=xn, svd_method=False)
+    gp.compute_log_likelihood(gp.hyperparameters, svd_method=False)
+    want = fresh(y, x, 2. * e)
+    assert not np.array_equal(gp.Prediction[0], p0)
+    assert np.array_equal(gp.Prediction[0], want[0]) and np.array_equal(gp.variance[0], want[1])
+    assert float(gp.log_likelihood[0]) == want[2]
+    gp.y[0][:] = y[::-1]                                # in place
+    gp.get_prediction(new_binning=xn, svd_method=False)
+    want = fresh(y[::-1], x, 2. * e)
+    assert np.array_equal(gp.Prediction[0], want[0])
