@@ -98,7 +98,7 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, no_dag = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, no_dag = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -121,6 +121,7 @@ struct CgpEnv {
         stream2 = getenv("CGP_STREAM2") != nullptr;
         debug = getenv("CGP_DEBUG") != nullptr;
         jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
+        jac_no_lowrank = getenv("CGP_JAC_NO_LOWRANK") != nullptr;
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
         dag_timeout_ms = num("CGP_DAG_TIMEOUT_MS", 4000);
@@ -196,6 +197,8 @@ struct cgp_handle {
     DevBuf bgrad;                             // 8 doubles: gradient moment sums
     // eigensolver route (svd_method=True): K, V, V diag(w), T = tall K^+, pivot Qs, flags, pair table, scalars
     DevBuf jK, jV, jVD, jT, jQ, jflags, jpairs, jstat, jlam, jres;
+    DevBuf lrGt, lrM, lrXt, lrY, lrws, lrldp, lrinfo, lrd, lrpart, lrctl;   // low-rank pre-stage of the eigen route (lowrank_pinv)
+    long last_rank = -1;                         // rank found by the pre-stage in the last eigen-route call (-1: full sweeps)
     long jnb = 0;                             // block count the pair table was built for
     int last_sweeps = 0;
     // batched state
@@ -739,7 +742,7 @@ int cgp_destroy(cgp_handle* h) {
     DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->dsticky, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
-                     &h->jstat, &h->jlam, &h->jres, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
+                     &h->jstat, &h->jlam, &h->jres, &h->lrGt, &h->lrM, &h->lrXt, &h->lrY, &h->lrws, &h->lrldp, &h->lrinfo, &h->lrd, &h->lrpart, &h->lrctl, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
                      &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
     for (DevBuf* b : all) free_buf(*b);
     for (auto& c : h->pin) (void)hipHostFree(c.p);
@@ -1453,14 +1456,13 @@ int cgp_batch_loo(cgp_handle* h, const double* kp, double* alpha, double* beta, 
 
 namespace {
 
-// Eigen route: h->jK holds the full symmetric Np x Np matrix (identity-padded, ld = Np).  Leaves the
-// pseudo-inverse (both triangles) in h->bC, logdet and the number of dropped modes in h->jres.
-int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
+// Jacobi sweeps: h->jK holds a full symmetric Np x Np matrix (identity-padded beyond n, ld = Np); on return its diagonal holds
+// the eigenvalues and h->jV the eigenvectors (columns).
+int jacobi_diagonalise(cgp_handle* h, long Np, long n) {
     const long nb = Np / JB, npairs = nb / 2, ld = Np;
     const size_t sq = (size_t)Np * Np * sizeof(double);
     CHK(ensure(h, h->jV, sq));
     CHK(ensure(h, h->jVD, sq));
-    CHK(ensure(h, h->bC, sq));
     CHK(ensure(h, h->jQ, (size_t)npairs * JP * JP * sizeof(double)));
     CHK(ensure(h, h->jflags, npairs * sizeof(int)));
     CHK(ensure(h, h->jstat, sizeof(JacStat)));
@@ -1497,13 +1499,6 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
         hipLaunchKernelGGL(k_jac_small, dim3(1), dim3(256), 0, h->stream, K, V, ld, (const JacStat*)st, 60);
         HIPCHK(hipGetLastError());
         h->last_sweeps = 1;
-        hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)K, (const double*)V,
-                           (double*)h->jVD.p, ld, (int)Np, (int)n, thresh, (double*)h->jlam.p, (double*)h->jres.p);
-        HIPCHK(hipGetLastError());
-        CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, (const double*)h->jVD.p, (const double*)h->jV.p, ld, 0, Np, Np, Np,
-                        true, 1.0, 0.0));
-        hipLaunchKernelGGL(k_mirror_lower, dim3(512), dim3(256), 0, h->stream, (double*)h->bC.p, ld, (int)Np);
-        HIPCHK(hipGetLastError());
         return 0;
     }
     // cyclic sweeps over a pivot matrix per visit: 1 (classical block-cyclic Jacobi) is the fastest -- the
@@ -1526,13 +1521,146 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
         int rot = 0;
         CHK(d2h(h, &rot, (char*)st + offsetof(JacStat, rotations), sizeof(int)));
         HIPCHK(stream_sync(h));
-        if (h->env.debug) fprintf(stderr, "cgp: eigen sweep %d: %d pivot blocks rotated\n", sweep, rot);
+        if (h->env.debug) fprintf(stderr, "cgp: eigen sweep %d (size %ld): %d pivot blocks rotated\n", sweep, Np, rot);
         if (rot == 0) break;
     }
     h->last_sweeps = sweep + 1;
     if (sweep == max_sweeps) return fail(h, CGP_E_STATE, "eigensolver: no convergence in 40 sweeps");
-    hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)K, (const double*)V,
-                       (double*)h->jVD.p, ld, (int)Np, (int)n, thresh, (double*)h->jlam.p, (double*)h->jres.p);
+    return 0;
+}
+
+// Low-rank pre-stage (jacobi.hpp): pivoted Cholesky of h->jK (left untouched) into Gt (r rows of Np), at most rcap steps.
+// *rank = r when the residual diagonal fell below the tolerance, -1 when it did not (full rank: the caller runs the full sweeps).
+int pivoted_cholesky(cgp_handle* h, long Np, long n, long rcap, long* rank) {
+    const long nparts = Np / PCHOL_ROWS;
+    CHK(ensure(h, h->lrGt, (size_t)round_up(rcap, NB) * Np * sizeof(double)));      // (lowrank_pinv pads the rank to a multiple of 128)
+    CHK(ensure(h, h->lrd, (size_t)Np * sizeof(double)));
+    CHK(ensure(h, h->lrpart, (size_t)2 * nparts * sizeof(double2)));
+    CHK(ensure(h, h->lrctl, sizeof(PcholCtl)));
+    const double* K = (const double*)h->jK.p;
+    double* Gt = (double*)h->lrGt.p;
+    double2* part = (double2*)h->lrpart.p;
+    PcholCtl* ctl = (PcholCtl*)h->lrctl.p;
+    hipLaunchKernelGGL(k_pchol_init, dim3(64), dim3(256), 0, h->stream, K, Np, (int)n, (int)Np, (double*)h->lrd.p, part, ctl, (int)nparts);
+    HIPCHK(hipGetLastError());
+    *rank = -1;
+    for (long j0 = 0; j0 < rcap; j0 += 64) {
+        const long j1 = std::min(rcap, j0 + 64);
+        for (long j = j0; j < j1; ++j)
+            hipLaunchKernelGGL(k_pchol_step, dim3((unsigned)nparts), dim3(256), 0, h->stream, K, Np, (int)n, Gt, Np, (double*)h->lrd.p,
+                               (const double2*)(part + (j & 1) * nparts), part + ((j + 1) & 1) * nparts, (int)nparts, (int)j, ctl);
+        HIPCHK(hipGetLastError());
+        PcholCtl c;
+        CHK(d2h(h, &c, ctl, sizeof(c)));
+        HIPCHK(stream_sync(h));
+        if (c.done) { *rank = c.rank; break; }
+        // a matrix of full rank (noisy data with the eigen route forced) never gets there: its residual diagonal stalls at the
+        // noise level.  A quarter of the way in, anything still above 1e-6 of the start is left to the full sweeps
+        if (j1 >= rcap / 4 && c.dcur > 1e-6 * c.dmax0) break;
+    }
+    return 0;
+}
+
+// K = G G^T + E (pivoted Cholesky, Gt = G^T in lrGt) -> pseudo-inverse in bC, by Rayleigh-Ritz on an ORTHONORMAL basis of
+// range(G):  Q = orth(G),  T = Q^T K Q = U S U^T (r x r, Jacobi sweeps),  K^+ = Q U S^-1 U^T Q^T over the modes S_p > thresh.
+// (Straight from G -- K^+ = G U S^-2 U^T G^T with G^T G = U S U^T -- is the same quantity in exact arithmetic but squares the
+// condition number: at a threshold of 1e-9 |K| its predictions were 30 x less accurate than the full sweeps', and at the
+// reference's 1e-15 useless; measured, tools/eig_lowrank_time.py.)  orth(G) = shifted Cholesky-QR, three passes (Fukaya et al.):
+// A = X^T X (+ shift in the first pass), A = R^T R, X := X R^-1 -- and "X R^-1 for all rows of X" is exactly what the blocked
+// Cholesky of this library does to its tall rows, so a pass is one GEMM plus one factor_range call on [A; X].
+int lowrank_pinv(cgp_handle* h, long Np, long n, long r, double thresh, int* ok) {
+    *ok = 0;
+    const long rp = round_up(r, NB), R = rp + Np, nblk = rp / NB;
+    CHK(ensure(h, h->lrM, (size_t)R * rp * sizeof(double)));
+    CHK(ensure(h, h->lrXt, (size_t)rp * Np * sizeof(double)));
+    CHK(ensure(h, h->lrY, (size_t)rp * Np * sizeof(double)));
+    CHK(ensure(h, h->lrws, (size_t)nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->lrldp, (size_t)nblk * sizeof(double)));
+    CHK(ensure(h, h->lrinfo, 2 * sizeof(int)));
+    Prob P;
+    P.B = 1; P.dim = 1; P.n = r; P.Np = rp; P.R = R; P.sM = R * rp;
+    P.M = (double*)h->lrM.p;
+    P.wsW = (double*)h->lrws.p; P.sW = nblk * 8 * 256;
+    P.ldp = (double*)h->lrldp.p; P.sLd = nblk;
+    P.info = (int*)h->lrinfo.p;
+    double* A = P.M;                          // rp x rp, ld = rp
+    double* X = P.M + rp * rp;                // Np x rp, ld = rp: the tall rows
+    double* Xt = (double*)h->lrXt.p;          // rp x Np
+    // X := G (rows of Gt beyond r are zero)
+    if (rp > r) HIPCHK(hipMemsetAsync((double*)h->lrGt.p + r * Np, 0, (size_t)(rp - r) * Np * sizeof(double), h->stream));
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)(Np / 32), (unsigned)(rp / 32)), dim3(256), 0, h->stream, (const double*)h->lrGt.p, Np,
+                       X, rp, (int)rp, (int)Np);
+    HIPCHK(hipGetLastError());
+    const double* src_t = (const double*)h->lrGt.p;
+    for (int pass = 0; pass < 3; ++pass) {
+        CHK(launch_gemm(h, 1, A, rp, 0, src_t, src_t, Np, 0, rp, rp, Np, true, 1.0, 0.0));
+        // shift of the first pass: 11 (m n + n (n + 1)) u |X|_2^2 with |X|_2^2 <= trace(A) (Fukaya et al., shifted CholeskyQR3)
+        hipLaunchKernelGGL(k_cholqr_prepare, dim3(1), dim3(256), 0, h->stream, A, rp, (int)r, (int)rp,
+                           pass == 0 ? 11. * ((double)Np * r + (double)r * (r + 1)) * 1.1102230246251565e-16 : 0.);
+        HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
+        HIPCHK(hipGetLastError());
+        CHK(factor_range(h, P, 0, rp, 0, R, true));          // A = L L^T in place, X := X L^-T
+        hipLaunchKernelGGL(k_transpose, dim3((unsigned)(rp / 32), (unsigned)(Np / 32)), dim3(256), 0, h->stream, (const double*)X, rp,
+                           Xt, Np, (int)Np, (int)rp);
+        HIPCHK(hipGetLastError());
+        src_t = Xt;
+    }
+    int info = 0;
+    CHK(d2h(h, &info, P.info, sizeof(int)));
+    HIPCHK(stream_sync(h));
+    if (info != 0) return 0;
+    // T = Q^T K Q: KQt = Qt K (rp x Np), T = KQt Qt^T (rp x rp) into the head of jK (K is not needed after KQt)
+    double* KQt = (double*)h->lrY.p;
+    CHK(launch_gemm(h, 1, KQt, Np, 0, Xt, (const double*)h->jK.p, Np, 0, rp, Np, Np, false, 1.0, 0.0));
+    CHK(launch_gemm(h, 1, (double*)h->jK.p, rp, 0, KQt, Xt, Np, 0, rp, rp, Np, true, 1.0, 0.0));
+    hipLaunchKernelGGL(k_sym_pad, dim3(512), dim3(256), 0, h->stream, (double*)h->jK.p, rp, (int)r, (int)rp);
+    HIPCHK(hipGetLastError());
+    CHK(jacobi_diagonalise(h, rp, r));
+    // B = U diag(1 / S) U^T over the kept modes; logdet; dropped = those + the n - r the factorisation left out
+    hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)h->jK.p, (const double*)h->jV.p,
+                       (double*)h->jVD.p, rp, (int)rp, (int)r, thresh, (double*)h->jlam.p, (double*)h->jres.p, 1, (double)(n - r));
+    HIPCHK(hipGetLastError());
+    double* Bm = (double*)h->jK.p;           // (the diagonalised T is consumed: B takes its place)
+    CHK(launch_gemm(h, 1, Bm, rp, 0, (const double*)h->jVD.p, (const double*)h->jV.p, rp, 0, rp, rp, rp, true, 1.0, 0.0));
+    hipLaunchKernelGGL(k_mirror_lower, dim3(512), dim3(256), 0, h->stream, Bm, rp, (int)rp);
+    HIPCHK(hipGetLastError());
+    // the padding modes of B (indices >= r, eigenvalue 1 of the padded T) must not reach K^+: Q has zero columns there
+    // Y = Q B (Np x rp), K^+ = Y Q^T (lower triangle, mirrored); the padding indices >= n of K^+ get their identity back
+    double* Y = (double*)h->lrGt.p;          // (G^T is consumed)
+    CHK(launch_gemm(h, 1, Y, rp, 0, (const double*)X, Bm, rp, 0, Np, rp, rp, false, 1.0, 0.0));
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, (const double*)Y, (const double*)X, rp, 0, Np, Np, rp, true, 1.0, 0.0));
+    hipLaunchKernelGGL(k_mirror_lower, dim3(512), dim3(256), 0, h->stream, (double*)h->bC.p, Np, (int)Np);
+    hipLaunchKernelGGL(k_pad_identity, dim3(256), dim3(256), 0, h->stream, (double*)h->bC.p, Np, (int)n, (int)Np);
+    HIPCHK(hipGetLastError());
+    *ok = 1;
+    return 0;
+}
+
+// Eigen route: h->jK holds the full symmetric Np x Np matrix (identity-padded, ld = Np).  Leaves the
+// pseudo-inverse (both triangles) in h->bC, logdet and the number of dropped modes in h->jres.
+int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
+    const long ld = Np;
+    const size_t sq = (size_t)Np * Np * sizeof(double);
+    CHK(ensure(h, h->bC, sq));
+    CHK(ensure(h, h->jres, 2 * sizeof(double)));
+    CHK(ensure(h, h->jlam, Np * sizeof(double)));
+    h->last_rank = -1;
+    if (n >= 256 && !h->env.jac_no_lowrank) {
+        // ---- low-rank pre-stage: noise-free kernel matrices (the ones this route exists for) are numerically rank deficient
+        const long rcap = std::min<long>(Np / 2, 2048);
+        long r = -1;
+        CHK(pivoted_cholesky(h, Np, n, rcap, &r));
+        if (h->env.debug) fprintf(stderr, "cgp: pivoted Cholesky of the %ld-point matrix: rank %ld (cap %ld)\n", n, r, rcap);
+        if (r > 0 && r <= rcap) {
+            int ok = 0;
+            CHK(lowrank_pinv(h, Np, n, r, thresh, &ok));
+            if (ok) { h->last_rank = r; return 0; }
+            // (a non-positive pivot in the orthonormalisation: the full sweeps take over, K is still in jK)
+        }
+    }
+    CHK(jacobi_diagonalise(h, Np, n));
+    hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)h->jK.p, (const double*)h->jV.p,
+                       (double*)h->jVD.p, ld, (int)Np, (int)n, thresh, (double*)h->jlam.p, (double*)h->jres.p, 1, 0.);
     HIPCHK(hipGetLastError());
     // K^+ = (V diag(w)) V^T : lower triangle by the MFMA GEMM, then mirrored
     CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, (const double*)h->jVD.p, (const double*)h->jV.p, ld, 0, Np, Np, Np,

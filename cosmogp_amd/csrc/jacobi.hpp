@@ -330,9 +330,11 @@ __global__ __launch_bounds__(256) void k_jac_apply(double* __restrict__ X0, doub
 // lambda_p = K[p][p]; w_p = 1 / lambda_p when |lambda_p| > thresh else 0; VD[:, p] = V[:, p] w_p.
 // res[0] = logdet = sum over kept of log |lambda_p|, res[1] = number of dropped modes among p < n
 // (padding modes are exact 1s: kept, log 1 = 0).  One workgroup computes the scalars (block 0), all scale.
+// power = 2 (low-rank route below): w_p = 1 / lambda_p^2; extra = modes already known to be dropped (added to res[1]).
 __global__ __launch_bounds__(256) void k_jac_finish(const double* __restrict__ K, const double* __restrict__ V,
                                                     double* __restrict__ VD, long ld, int Np, int n, double thresh,
-                                                    double* __restrict__ lam_out, double* __restrict__ res) {
+                                                    double* __restrict__ lam_out, double* __restrict__ res, int power = 1,
+                                                    double extra = 0.) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
         __shared__ double red[2][4];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void k_jac_finish(const double* __restrict__ K
         __syncthreads();
         if (tid == 0) {
             res[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-            res[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            res[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3] + extra;
         }
     }
     const long tot = (long)Np * Np / 2;
@@ -357,7 +359,10 @@ __global__ __launch_bounds__(256) void k_jac_finish(const double* __restrict__ K
         const long r = idx / (Np / 2), c = (idx - r * (Np / 2)) * 2;
         const double l0 = K[c * ld + c], l1 = K[(c + 1) * ld + c + 1];
         const double2 v = *(const double2*)(V + r * ld + c);
-        *(double2*)(VD + r * ld + c) = make_double2(fabs(l0) > thresh ? v.x / l0 : 0., fabs(l1) > thresh ? v.y / l1 : 0.);
+        const double w0 = fabs(l0) > thresh ? (power == 2 ? 1. / (l0 * l0) : 1. / l0) : 0.;
+        const double w1 = fabs(l1) > thresh ? (power == 2 ? 1. / (l1 * l1) : 1. / l1) : 0.;
+        *(double2*)(VD + r * ld + c) = make_double2(power == 2 ? v.x * w0 : (fabs(l0) > thresh ? v.x / l0 : 0.),
+                                                    power == 2 ? v.y * w1 : (fabs(l1) > thresh ? v.y / l1 : 0.));
     }
 }
 
@@ -415,5 +420,190 @@ __global__ __launch_bounds__(256) void k_finish_pinv(
             scal[0] = -0.5 * s1 - 0.5 * n * 1.8378770664093453 - 0.5 * res[0];
             scal[1] = res[0];
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Low-rank pre-stage of the eigen route (round 3).  The route runs when the data carry no noise (with noise the Cholesky route
+// serves svd_method=True, gaussian_process.SVD_VIA_CHOLESKY_WHEN_PD), and a noise-free RBF matrix is numerically of LOW RANK:
+// N = 4096 points on a domain of 200 length scales have 541 eigenvalues above 1e-13 |K| -- everything below is the rounding
+// noise of any decomposition.  Diagonally pivoted Cholesky  K = G G^T + E,  max_i E_ii <= tol = 4 eps max_i K_ii, after r << N
+// steps; then the r x r problem  G^T G = U S U^T  (same non-zero spectrum as G G^T) on the Jacobi sweeps above, and
+//     K^+ = G U S^-2 U^T G^T   (modes S_p > thresh),   logdet = sum log S_p,   dropped = (n - r) + #{S_p <= thresh}.
+// One kernel per step: every workgroup re-reduces the previous step's per-workgroup maxima of the residual diagonal d (pivot
+// p), computes its 64 rows of column j,  g_i = (K_ip - sum_{c<j} G_ic G_pc) / sqrt(d_p)  (G stored transposed: row c of Gt is
+// column c of G, contiguous in i), updates d and leaves its own maximum for the next step.  A matrix that does not reach
+// the tolerance within rcap steps (full rank: noisy data with the eigen route forced) goes to the full sweeps unchanged.
+// ------------------------------------------------------------------------------------------------------------------
+struct PcholCtl {
+    int done;            // 1: the residual diagonal fell below the tolerance at step `rank`
+    int rank;
+    double tol;          // absolute tolerance on the residual diagonal
+    double dmax0;        // largest diagonal entry at the start
+    double dcur;         // largest residual diagonal entry at the last step taken (the host gives up on matrices of full rank)
+};
+
+#define PCHOL_ROWS 64
+
+// d := diag(K) (rows < n; -1 beyond), per-workgroup maxima, tolerance
+__global__ __launch_bounds__(256) void k_pchol_init(const double* __restrict__ K, long ld, int n, int Np, double* __restrict__ d,
+                                                    double2* __restrict__ part, PcholCtl* __restrict__ ctl, int nparts) {
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    double best = -1.;
+    int bi = 0;
+    for (int i = blockIdx.x * 256 + tid; i < Np; i += gridDim.x * 256) {
+        const double v = i < n ? K[(long)i * ld + i] : -1.;
+        d[i] = v;
+    }
+    // (grid = Np / PCHOL_ROWS workgroups would be wasteful here: one workgroup does the scalars after a grid-wide pass is
+    //  not possible, so workgroup 0 recomputes the maxima of every 64-row group itself)
+    if (blockIdx.x == 0) {
+        for (int g = 0; g < nparts; ++g) {
+            double m = -1.;
+            int mi = g * PCHOL_ROWS;
+            if (tid < PCHOL_ROWS) {
+                const int i = g * PCHOL_ROWS + tid;
+                m = i < n ? K[(long)i * ld + i] : -1.;
+                mi = i;
+            }
+            sv[tid] = m; si[tid] = mi;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (tid < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
+                    sv[tid] = sv[tid + off]; si[tid] = si[tid + off];
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                part[g] = make_double2(sv[0], (double)si[0]);
+                if (sv[0] > best) { best = sv[0]; bi = si[0]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            ctl->done = 0; ctl->rank = 0;
+            ctl->dmax0 = best;
+            ctl->dcur = best;
+            ctl->tol = 4. * 2.220446049250313e-16 * best;
+            (void)bi;
+        }
+    }
+}
+
+// step j: grid = Np / PCHOL_ROWS workgroups of 256 threads (64 rows x 4 partitions of the sum over c)
+__global__ __launch_bounds__(256) void k_pchol_step(const double* __restrict__ K, long ld, int n, double* __restrict__ Gt, long ldg,
+                                                    double* __restrict__ d, const double2* __restrict__ part_in,
+                                                    double2* __restrict__ part_out, int nparts, int j, PcholCtl* __restrict__ ctl) {
+    __shared__ double sacc[4][PCHOL_ROWS];
+    __shared__ double sv[PCHOL_ROWS];
+    __shared__ int si[PCHOL_ROWS];
+    __shared__ double s_p[2];
+    if (ctl->done) return;
+    const int tid = threadIdx.x, rr = tid & 63, q = tid >> 6;
+    // pivot: the largest residual diagonal entry (lowest index on ties), the same in every workgroup
+    if (tid < 64) {
+        double m = -1.;
+        int mi = 0x7fffffff;
+        for (int g = tid; g < nparts; g += 64) {
+            const double2 v = part_in[g];
+            if (v.x > m || (v.x == m && (int)v.y < mi)) { m = v.x; mi = (int)v.y; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double om = __shfl_down(m, off);
+            const int oi = __shfl_down(mi, off);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        if (tid == 0) { s_p[0] = m; s_p[1] = (double)mi; }
+    }
+    __syncthreads();
+    const double dp = s_p[0];
+    const int p = (int)s_p[1];
+    if (!(dp > ctl->tol)) {
+        if (blockIdx.x == 0 && tid == 0) { ctl->rank = j; ctl->done = 1; }
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) ctl->dcur = dp;
+    const int i = blockIdx.x * PCHOL_ROWS + rr;
+    double acc = 0.;
+    for (int c = q; c < j; c += 4) acc = fma(Gt[(long)c * ldg + i], Gt[(long)c * ldg + p], acc);
+    sacc[q][rr] = acc;
+    __syncthreads();
+    if (tid < PCHOL_ROWS) {
+        const double s = (sacc[0][rr] + sacc[1][rr]) + (sacc[2][rr] + sacc[3][rr]);
+        double g = 0., dn = -1.;
+        if (i < n) {
+            g = (K[(long)p * ld + i] - s) / sqrt(dp);           // (K symmetric: row p is column p, contiguous in i)
+            const double dold = d[i];
+            if (dold < 0.) dn = dold;                              // an earlier pivot stays out
+            else if (i == p) dn = -1.;                             // the pivot is never chosen again
+            else dn = fmax(dold - g * g, 0.);                      // (rounding below zero: exhausted, not negative)
+            d[i] = dn;
+        }
+        Gt[(long)j * ldg + i] = g;
+        sv[rr] = dn; si[rr] = i;
+    }
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        if (tid < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
+            sv[tid] = sv[tid + off]; si[tid] = si[tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) part_out[blockIdx.x] = make_double2(sv[0], (double)si[0]);
+}
+
+// dst (cols x rows, ld = ldd) := src^T (rows x cols, ld = lds), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int rows, int cols) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < rows && bx + tx < cols) t[r][tx] = src[(long)(by + r) * lds_ + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < cols && by + tx < rows) dst[(long)(bx + r) * ldd + by + tx] = t[tx][r];
+}
+
+// A (rp x rp, lower triangle given) -> full symmetric with the identity on the padding indices >= r
+__global__ void k_sym_pad(double* __restrict__ A, long ld, int r, int rp) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = (long)rp * rp;
+    for (; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+        const long i = idx / rp, c = idx - i * rp;
+        if (i >= r || c >= r) A[i * ld + c] = i == c ? 1. : 0.;
+        else if (c > i) A[i * ld + c] = A[c * ld + i];
+    }
+}
+
+// rows / columns >= n of an Np x Np matrix := those of the identity (the padding of the pseudo-inverse)
+__global__ void k_pad_identity(double* __restrict__ A, long ld, int n, int Np) {
+    const long npad = Np - n;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tot = npad * Np;
+    for (; idx < tot; idx += (long)gridDim.x * blockDim.x) {
+        const long q = idx / Np, c = idx - q * Np, i = n + q;
+        A[i * ld + c] = i == c ? 1. : 0.;           // row i >= n
+        if (c < n) A[c * ld + i] = 0.;              // column i >= n above the padding rows
+    }
+}
+
+// A (rp x rp, lower triangle from the GEMM) before a Cholesky-QR pass: the padding diagonal (indices >= r) := 1 (X has zero
+// columns there), the diagonal += shift * trace(A) over the r real indices
+__global__ __launch_bounds__(256) void k_cholqr_prepare(double* __restrict__ A, long ld, int r, int rp, double shift) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double t = 0.;
+    for (int i = tid; i < r; i += 256) t += A[(long)i * ld + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+    __syncthreads();
+    const double s = shift * ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = tid; i < rp; i += 256) {
+        if (i < r) A[(long)i * ld + i] += s;
+        else A[(long)i * ld + i] = 1.;
     }
 }

@@ -163,3 +163,65 @@ def test_auto_route_selection(cg):
     assert len(calls) == 1 and np.all(np.isfinite(g0.Prediction[0]))
     with pytest.raises(np.linalg.LinAlgError):
         g0.get_prediction(new_binning=np.linspace(0., 20., 40), svd_method=False)
+
+
+def test_low_rank_pre_stage_equals_full_sweeps(cg, monkeypatch):
+    """Noise-free kernel matrices are numerically of low rank; from 256 points on the eigen route first runs a pivoted Cholesky
+    (rank r), orthonormalises its factor (shifted Cholesky-QR) and diagonalises the r x r Rayleigh-Ritz matrix instead of sweeping
+    the N x N one (csrc/jacobi.hpp).  With a threshold above the rounding noise (1e-9 |K|: the reference's absolute 1e-15 sits below
+    it for a matrix of this scale, where K^+ is not reproducible by ANY method) the two must agree: same kept / dropped split,
+    same log-determinant, same K^+ y for a y in the range of K."""
+    from cosmogp_amd import _lib
+    n = 700
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(0., 70., n))
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 4.)
+    y = K @ (np.sin(0.3 * x) + 0.5 * np.cos(0.11 * x))
+    out = {}
+    for mode in ('lowrank', 'full'):
+        if mode == 'full':
+            monkeypatch.setenv('CGP_JAC_NO_LOWRANK', '1')
+        else:
+            monkeypatch.delenv('CGP_JAC_NO_LOWRANK', raising=False)
+        dev = _lib.Device(0)
+        out[mode] = dev.svd_inverse(K, thresh=1e-9)
+        dev.close()
+    (il, ll, dl), (if_, lf, df) = out['lowrank'], out['full']
+    w = np.linalg.eigvalsh(K)
+    assert dl == df == int(np.sum(w <= 1e-9)) and dl > n // 2            # really rank deficient, same split
+    # (the smallest kept eigenvalues, ~1e-9, carry absolute errors of ~eps |K| = 1e-14 in every method: 1e-5 in their logarithm)
+    assert abs(ll - lf) <= 1e-4 and abs(ll - np.sum(np.log(w[w > 1e-9]))) <= 1e-4
+    al, af = il @ y, if_ @ y
+    assert np.abs(K @ al - y).max() <= 1e-6 * np.abs(y).max()
+    assert np.abs(K @ af - y).max() <= 1e-6 * np.abs(y).max()
+    # (alpha = K^+ y itself is ill-conditioned at this threshold -- its components along the 1e-9 modes carry eps |y| / 1e-9 --
+    # the prediction H alpha is not)
+    xs = np.linspace(1., 69., 40)
+    H = np.exp(-0.5 * (xs[:, None] - x[None, :]) ** 2 / 4.)
+    np.testing.assert_allclose(H @ al, H @ af, rtol=0, atol=1e-6 * np.abs(H @ af).max())
+    np.testing.assert_allclose(il, il.T, rtol=0, atol=1e-9 * np.abs(il).max())
+    # full rank (noise on the diagonal): the pre-stage gives up and the full sweeps answer, as before
+    monkeypatch.delenv('CGP_JAC_NO_LOWRANK', raising=False)
+    dev = _lib.Device(0)
+    Kn = K[:300, :300] + 1e-2 * np.eye(300)
+    inv, ld, nd = dev.svd_inverse(Kn)
+    dev.close()
+    assert nd == 0 and np.abs(Kn @ inv - np.eye(300)).max() < 1e-9
+
+
+def test_noise_free_prediction_through_the_classes(cg):
+    """The reference's default call (svd_method=True) on noise-free data of 400 points, small amplitude (so that the absolute
+    1e-15 threshold lies above the rounding noise and the kept / dropped split is a property of the matrix): prediction and
+    variance against the oracle's truncated-SVD route."""
+    n = 400
+    rng = np.random.default_rng(8)
+    x = np.sort(rng.uniform(0., 40., n))
+    hyp = [0.004, 1.5]
+    y = 0.004 * (np.sin(0.7 * x) + 0.3 * np.cos(1.9 * x))
+    xn = np.linspace(1., 39., 23)
+    gp = cg.gaussian_process(y, x, kernel='RBF1D')
+    gp.hyperparameters = np.array(hyp)
+    gp.get_prediction(new_binning=xn)                     # svd_method=True by default; no noise: the eigen route
+    want = orc.predict([y], [x], 'RBF1D', hyp, 0., [np.zeros(n)], new_binning=xn, svd_method=True)
+    np.testing.assert_allclose(gp.Prediction[0], want['prediction'][0], rtol=0, atol=1e-6 * hyp[0])
+    np.testing.assert_allclose(gp.variance[0], np.diag(want['covariance'][0]), rtol=0, atol=1e-6 * hyp[0] ** 2)
