@@ -5,7 +5,7 @@ tag=${1:-r03}
 export TMPDIR=/tmp
 root=$(pwd)
 mkdir -p gpurun_out
-args="--no-extras --no-cpu-baseline --steps 24 --warmup 0"
+args="--no-extras --no-cpu-baseline --steps 3 --warmup 0"
 # SQ passes (8 SQ slots per pass)
 (cd /tmp && rm -rf /tmp/pmc_sq1 && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq1 -o run --output-format csv -- python3 $root/bench.py $args > /tmp/pmc_sq1.log 2>&1) || { tail -5 /tmp/pmc_sq1.log; exit 1; }
 python3 tools/pmc_sq.py $(find /tmp/pmc_sq1 -name "*counter_collection.csv" | head -1) gpurun_out/${tag}_pmc_sq_a.csv
