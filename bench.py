@@ -4,9 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: assemble K (RBF), blocked Cholesky with the cross matrix and the residual riding along
+in HBM -- the objects of ONE launch sequence: 8 distinct objects for c3, 16 for c2, 128 for c4, 4 candidates for c5
+(`config.fits_per_step_per_gpu`) --: assemble K (RBF), blocked Cholesky with the cross matrix and the residual riding along
 as tall rows, predictive mean + variance at M points, log-likelihood.  No host copies inside the
-timed region (the PCIe-inclusive rate is noted in DESIGN.md, it is never `value`).
+timed region (`value` is device-resident fits/s; the PCIe-inclusive rate is `roofline.api_fits_per_sec`, it is never `value`).
 
 Workloads (seeds fixed):
   c3 (default at N=1)  2D RBF GP, N=8192, M=2500, single fit     -- the size BASELINE.json's metric names
@@ -19,8 +20,10 @@ plainly starts its N ranks itself (child processes, spawned before the parent to
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's RANK / LOCAL_RANK /
 WORLD_SIZE are used as they are.
 
-Rank 0 prints ONE JSON line.  roofline = the dominant kernel (k_gemm_nt, fp64 MFMA): algorithmic
-flops per launch / average launch duration measured with HIP events on the kernel's own stream.
+Rank 0 prints ONE JSON line.  roofline = the dominant kernel (k_chol_dag, the persistent tile-DAG launch; k_gemm_nt on the
+launch-per-step route of small objects; fp64 MFMA): algorithmic flops per launch / average launch duration measured with HIP
+events on the kernel's own stream; roofline.single_fit / single_fit_n4096 = one fit at a time at N = 8192 / 4096.
+Launched as a rank, config.rccl_ranks = ncclCommCount and extra.multi_gpu = BASELINE configs 4 and 5 over the ranks.
 cpu_baseline = the CPU oracle (NumPy/SciPy restatement of the reference) on the host cores, N=1 only.
 """
 import argparse
