@@ -432,8 +432,8 @@ class FileComm(object):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 10; c4: 200 -- its step is 0.35 ms)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps before them (default 2; c4: 20)')
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
@@ -451,6 +451,10 @@ def main():
                          'buffers); 0 = auto: 2 when c2 / c3 run in lock-step batches (--batch), 4 with --batch 1, '
                          '4 for c4 (232k -> 290k fits/s), 1 for the lock-step sweep')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == 'c4' else 10
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == 'c4' else 2
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # not under a launcher: this process only starts the ranks (it never initialises HIP)

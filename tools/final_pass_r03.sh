@@ -25,5 +25,5 @@ else
   echo "stats c4 done"
   ./tools/r03_pmc.sh final/r03 && echo "pmc done"
   # config 4 again with a timed region of ~80 ms (the default 10 steps are 4 ms: start-up effects of four host threads show)
-  timeout -k 10 400 python3 bench.py --workload c4 --steps 200 --warmup 20 > $out/r03_bench_final_c4.json 2> $out/bench_c4b.err && echo "bench c4 (200 steps) done"
+  timeout -k 10 400 python3 bench.py --workload c4 > $out/r03_bench_final_c4.json 2> $out/bench_c4b.err && echo "bench c4 (200 steps) done"
 fi
