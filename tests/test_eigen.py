@@ -225,3 +225,38 @@ def test_noise_free_prediction_through_the_classes(cg):
     want = orc.predict([y], [x], 'RBF1D', hyp, 0., [np.zeros(n)], new_binning=xn, svd_method=True)
     np.testing.assert_allclose(gp.Prediction[0], want['prediction'][0], rtol=0, atol=1e-6 * hyp[0])
     np.testing.assert_allclose(gp.variance[0], np.diag(want['covariance'][0]), rtol=0, atol=1e-6 * hyp[0] ** 2)
+
+
+@pytest.mark.parametrize('ell', [3.0, 0.45])
+def test_noise_free_prediction_rank_below_and_above_the_cap(cg, ell, monkeypatch):
+    """Noise-free, 320 points on 40 units, small amplitude (so that the reference's absolute 1e-15 threshold lies above the rounding
+    noise): with length scale 3 the matrix has a few dozen resolved modes and the low-rank pre-stage answers; with 0.45 its
+    numerical rank exceeds the cap of N / 2 pivoted-Cholesky steps and the full sweeps must take over from an UNTOUCHED K.  Either
+    way the prediction equals the oracle's truncated-SVD route.  (1D on purpose: the reference's 2D train-train matrix carries no
+    sigma^2, kernel.py:146, so a 2D matrix always has scale 1 and its 1e-15 modes are rounding noise.)"""
+    from cosmogp_amd import _lib
+    n = 320
+    rng = np.random.default_rng(21)
+    x = np.sort(rng.uniform(0., 40., n))
+    sig = 0.004
+    hyp = [sig, ell]
+    y = sig * (np.sin(0.4 * x) + 0.4 * np.cos(1.3 * x))
+    xn = np.linspace(1., 39., 21)
+    dev = _lib.Device(0)
+    gp = cg.gaussian_process(y, x, kernel='RBF1D', device=dev)
+    gp.hyperparameters = np.array(hyp)
+    gp.get_prediction(new_binning=xn)                      # svd_method=True, no noise: the eigen route
+    want = orc.predict([y], [x], 'RBF1D', hyp, 0., [np.zeros(n)], new_binning=xn, svd_method=True)
+    # (length scale 0.45: dozens of modes crowd around the threshold, the kept / dropped split of two decompositions differs by
+    # a mode or two and the prediction by a few 1e-6 sigma)
+    np.testing.assert_allclose(gp.Prediction[0], want['prediction'][0], rtol=0, atol=(2e-6 if ell > 1. else 1e-5) * sig)
+    dev.close()
+    if ell < 1.:
+        # the pre-stage gave up: the answer must be bit for bit that of the full sweeps alone
+        monkeypatch.setenv('CGP_JAC_NO_LOWRANK', '1')
+        dev2 = _lib.Device(0)
+        g2 = cg.gaussian_process(y, x, kernel='RBF1D', device=dev2)
+        g2.hyperparameters = np.array(hyp)
+        g2.get_prediction(new_binning=xn)
+        assert np.array_equal(g2.Prediction[0], gp.Prediction[0]) and np.array_equal(g2.variance[0], gp.variance[0])
+        dev2.close()
