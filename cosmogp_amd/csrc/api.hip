@@ -1541,7 +1541,7 @@ int pivoted_cholesky(cgp_handle* h, long Np, long n, long rcap, long* rank) {
     double* Gt = (double*)h->lrGt.p;
     double2* part = (double2*)h->lrpart.p;
     PcholCtl* ctl = (PcholCtl*)h->lrctl.p;
-    hipLaunchKernelGGL(k_pchol_init, dim3(64), dim3(256), 0, h->stream, K, Np, (int)n, (int)Np, (double*)h->lrd.p, part, ctl, (int)nparts);
+    hipLaunchKernelGGL(k_pchol_init, dim3(1), dim3(256), 0, h->stream, K, Np, (int)n, (int)Np, (double*)h->lrd.p, part, ctl, (int)nparts);
     HIPCHK(hipGetLastError());
     *rank = -1;
     for (long j0 = 0; j0 < rcap; j0 += 64) {

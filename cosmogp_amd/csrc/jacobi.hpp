@@ -446,50 +446,37 @@ struct PcholCtl {
 
 #define PCHOL_ROWS 64
 
-// d := diag(K) (rows < n; -1 beyond), per-workgroup maxima, tolerance
+// d := diag(K) (rows < n; -1 beyond: never a pivot) and the maximum of every 64-row group; ONE workgroup (the diagonal is N
+// doubles), which also sets the tolerance 4 eps max_i K_ii
 __global__ __launch_bounds__(256) void k_pchol_init(const double* __restrict__ K, long ld, int n, int Np, double* __restrict__ d,
                                                     double2* __restrict__ part, PcholCtl* __restrict__ ctl, int nparts) {
     __shared__ double sv[256];
     __shared__ int si[256];
     const int tid = threadIdx.x;
     double best = -1.;
-    int bi = 0;
-    for (int i = blockIdx.x * 256 + tid; i < Np; i += gridDim.x * 256) {
+    for (int g0 = 0; g0 < nparts; g0 += 4) {
+        // four groups of 64 rows per pass: thread tid looks at row (g0 + tid / 64) * 64 + tid % 64
+        const int i = g0 * PCHOL_ROWS + tid;
         const double v = i < n ? K[(long)i * ld + i] : -1.;
-        d[i] = v;
+        if (i < Np) d[i] = v;
+        sv[tid] = v; si[tid] = i;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {            // reduce inside each group of 64 (lowest index wins ties)
+            if ((tid & 63) < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
+                sv[tid] = sv[tid + off]; si[tid] = si[tid + off];
+            }
+            __syncthreads();
+        }
+        if ((tid & 63) == 0 && g0 + (tid >> 6) < nparts) part[g0 + (tid >> 6)] = make_double2(sv[tid], (double)si[tid]);
+        if (tid == 0)
+            for (int q = 0; q < 4; ++q) best = fmax(best, sv[64 * q]);
+        __syncthreads();
     }
-    // (grid = Np / PCHOL_ROWS workgroups would be wasteful here: one workgroup does the scalars after a grid-wide pass is
-    //  not possible, so workgroup 0 recomputes the maxima of every 64-row group itself)
-    if (blockIdx.x == 0) {
-        for (int g = 0; g < nparts; ++g) {
-            double m = -1.;
-            int mi = g * PCHOL_ROWS;
-            if (tid < PCHOL_ROWS) {
-                const int i = g * PCHOL_ROWS + tid;
-                m = i < n ? K[(long)i * ld + i] : -1.;
-                mi = i;
-            }
-            sv[tid] = m; si[tid] = mi;
-            __syncthreads();
-            for (int off = 128; off > 0; off >>= 1) {
-                if (tid < off && (sv[tid + off] > sv[tid] || (sv[tid + off] == sv[tid] && si[tid + off] < si[tid]))) {
-                    sv[tid] = sv[tid + off]; si[tid] = si[tid + off];
-                }
-                __syncthreads();
-            }
-            if (tid == 0) {
-                part[g] = make_double2(sv[0], (double)si[0]);
-                if (sv[0] > best) { best = sv[0]; bi = si[0]; }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            ctl->done = 0; ctl->rank = 0;
-            ctl->dmax0 = best;
-            ctl->dcur = best;
-            ctl->tol = 4. * 2.220446049250313e-16 * best;
-            (void)bi;
-        }
+    if (tid == 0) {
+        ctl->done = 0; ctl->rank = 0;
+        ctl->dmax0 = best;
+        ctl->dcur = best;
+        ctl->tol = 4. * 2.220446049250313e-16 * best;
     }
 }
 
