@@ -761,9 +761,30 @@ def main():
             assert np.array_equal(out_p[0], out_l[0]) and np.array_equal(out_p[2], out_l[2])       # same bits either way
             extra['api_fits_per_sec'] = round(rate_p, 2)
             extra['api_fits_per_sec_lists'] = round(rate_l, 2)
+            # two callers, one handle each (the binding releases the GIL inside the call): one caller's upload and download
+            # run under the other's device pass
+            import threading
+            ncall = max(2, int(os.environ.get('CGP_BENCH_API_CALLERS', '2')))
+            callers = [adev] + [_lib.Device(local_rank) for _ in range(ncall - 1)]
+            for c_ in callers:
+                c_.batch_fit(1, px, py, pd, wl['kp'], wl['xnew'], None, 0.)
+            reps_t = 16
+
+            def caller(c_):
+                for _ in range(reps_t):
+                    c_.batch_fit(1, px, py, pd, wl['kp'], wl['xnew'], None, 0.)
+            ths = [threading.Thread(target=caller, args=(c_,)) for c_ in callers]
+            t_a = time.perf_counter()
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+            extra['api_fits_per_sec_%dcallers' % ncall] = round(len(callers) * reps_t * wl['B'] / (time.perf_counter() - t_a), 2)
+            for c_ in callers[1:]:
+                c_.close()
             extra['api_note'] = ('cgp_batch_fit with host arrays in (upload of all %d objects: coordinates, residuals, diagonals as '
                                  'one (B, n) array each) and loglik / mu / var back on the host, ONE handle, one call after the '
-                                 'other; _lists: the same from lists of per-object arrays' % wl['B'])
+                                 'other; _lists: the same from lists of per-object arrays; _<k>callers: k host threads with a handle each' % wl['B'])
         else:
             def api_one():
                 adev.set_data(wl['dim'], wl['x'], wl['y'])
