@@ -1592,12 +1592,12 @@ int lowrank_pinv(cgp_handle* h, long Np, long n, long r, double thresh, int* ok)
                        X, rp, (int)rp, (int)Np);
     HIPCHK(hipGetLastError());
     const double* src_t = (const double*)h->lrGt.p;
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));      // (sticky over the three passes: the first bad pivot counts)
     for (int pass = 0; pass < 3; ++pass) {
         CHK(launch_gemm(h, 1, A, rp, 0, src_t, src_t, Np, 0, rp, rp, Np, true, 1.0, 0.0));
         // shift of the first pass: 11 (m n + n (n + 1)) u |X|_2^2 with |X|_2^2 <= trace(A) (Fukaya et al., shifted CholeskyQR3)
         hipLaunchKernelGGL(k_cholqr_prepare, dim3(1), dim3(256), 0, h->stream, A, rp, (int)r, (int)rp,
                            pass == 0 ? 11. * ((double)Np * r + (double)r * (r + 1)) * 1.1102230246251565e-16 : 0.);
-        HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
         HIPCHK(hipGetLastError());
         CHK(factor_range(h, P, 0, rp, 0, R, true));          // A = L L^T in place, X := X L^-T
         hipLaunchKernelGGL(k_transpose, dim3((unsigned)(rp / 32), (unsigned)(Np / 32)), dim3(256), 0, h->stream, (const double*)X, rp,
