@@ -19,7 +19,7 @@ MAT_K, MAT_L, MAT_KINV = 0, 1, 2
 #: every symbol include/cosmogp_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     'cgp_version', 'cgp_device_count', 'cgp_create', 'cgp_destroy', 'cgp_last_error',
-    'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
+    'cgp_synchronize', 'cgp_rbf', 'cgp_cholesky_inverse', 'cgp_svd_inverse', 'cgp_eig_info', 'cgp_fit_set_data', 'cgp_fit', 'cgp_fit_svd',
     'cgp_fit_predict', 'cgp_fit_grad', 'cgp_fit_fetch', 'cgp_batch_set_data', 'cgp_batch_fit', 'cgp_batch_fit_grad', 'cgp_batch_loo', 'cgp_sweep_loglik',
     'cgp_comm_unique_id', 'cgp_comm_init', 'cgp_comm_destroy', 'cgp_comm_count', 'cgp_comm_allgather', 'cgp_comm_allreduce',
     'cgp_sweep_loglik_sharded', 'cgp_bispev', 'cgp_bench_fit', 'cgp_bench_fit_objects', 'cgp_microbench',
@@ -82,6 +82,7 @@ def load_library():
         lib.cgp_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
         lib.cgp_comm_destroy.argtypes = [vp]
         lib.cgp_comm_count.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+        lib.cgp_eig_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
         lib.cgp_comm_allgather.argtypes = [vp, _dp, _i64, _dp]
         lib.cgp_comm_allreduce.argtypes = [vp, _dp, _i64, ctypes.c_int]
         lib.cgp_sweep_loglik_sharded.argtypes = [vp, _i64, _dp, _dp, _i64, _dp, ctypes.POINTER(ctypes.c_int32)]
@@ -411,6 +412,13 @@ class Device(object):
 
     def comm_destroy(self):
         self._check(self._lib.cgp_comm_destroy(self._h), 'cgp_comm_destroy')
+
+    def eig_info(self):
+        """(route, rank, sweeps) of the last eigen-route call: route 0 = Jacobi sweeps, 1 = low-rank pre-stage, 2 = certified
+        Cholesky (include/cosmogp_hip.h, cgp_eig_info)."""
+        out = (ctypes.c_int64 * 3)()
+        self._check(self._lib.cgp_eig_info(self._h, out), 'cgp_eig_info')
+        return int(out[0]), int(out[1]), int(out[2])
 
     def comm_count(self):
         """Ranks the RCCL communicator of this handle reports (ncclCommCount)."""

@@ -96,9 +96,9 @@ enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_G
 // CGP_* diagnostic switches, read ONCE per handle at cgp_create
 struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
-    double jac_tol = 1.0;
+    double jac_tol = 1.0, eig_cond_max = 1e10;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, no_dag = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -122,6 +122,8 @@ struct CgpEnv {
         debug = getenv("CGP_DEBUG") != nullptr;
         jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
         jac_no_lowrank = getenv("CGP_JAC_NO_LOWRANK") != nullptr;
+        eig_no_chol = getenv("CGP_EIG_NO_CHOL") != nullptr;
+        if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
         dag_timeout_ms = num("CGP_DAG_TIMEOUT_MS", 4000);
@@ -198,6 +200,9 @@ struct cgp_handle {
     // eigensolver route (svd_method=True): K, V, V diag(w), T = tall K^+, pivot Qs, flags, pair table, scalars
     DevBuf jK, jV, jVD, jT, jQ, jflags, jpairs, jstat, jlam, jres;
     DevBuf lrGt, lrM, lrXt, lrY, lrws, lrldp, lrinfo, lrd, lrpart, lrctl;   // low-rank pre-stage of the eigen route (lowrank_pinv)
+    DevBuf lrcert;                               // full-rank shortcut (chol_certified_pinv): partial sums + CholCert
+    double lr_dmax0 = 0.;                        // largest diagonal entry the pivoted Cholesky started from
+    int last_route = 0;                          // last eigen-route call: 0 sweeps, 1 low-rank pre-stage, 2 certified Cholesky
     long last_rank = -1;                         // rank found by the pre-stage in the last eigen-route call (-1: full sweeps)
     long jnb = 0;                             // block count the pair table was built for
     int last_sweeps = 0;
@@ -1553,7 +1558,7 @@ int pivoted_cholesky(cgp_handle* h, long Np, long n, long rcap, long* rank) {
         PcholCtl c;
         CHK(d2h(h, &c, ctl, sizeof(c)));
         HIPCHK(stream_sync(h));
-        if (c.done) { *rank = c.rank; break; }
+        if (c.done) { *rank = c.rank; h->lr_dmax0 = c.dmax0; break; }
         // a matrix of full rank (noisy data with the eigen route forced) never gets there: its residual diagonal stalls at the
         // noise level.  A quarter of the way in, anything still above 1e-6 of the start is left to the full sweeps
         if (j1 >= rcap / 4 && c.dcur > 1e-6 * c.dmax0) break;
@@ -1591,6 +1596,18 @@ int lowrank_pinv(cgp_handle* h, long Np, long n, long r, double thresh, int* ok)
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)(Np / 32), (unsigned)(rp / 32)), dim3(256), 0, h->stream, (const double*)h->lrGt.p, Np,
                        X, rp, (int)rp, (int)Np);
     HIPCHK(hipGetLastError());
+    // The factorisation stops on the residual DIAGONAL, which bounds the residual only for a positive semi-definite matrix
+    // (|E_ij|^2 <= E_ii E_jj, |E|_F <= trace E <= n tol).  svd_inverse takes any symmetric matrix (s = |lambda|): an
+    // indefinite one runs out of positive pivots with most of itself still in E.  So E = K - G G^T is formed (bC is free) and
+    // its norm read with the passes' result below: beyond the rounding of the product itself the sweeps take over.
+    CHK(ensure(h, h->jstat, sizeof(JacStat)));
+    CHK(ensure(h, h->lrcert, (size_t)(2 * JAC_NORM_BLOCKS) * sizeof(double) + sizeof(CholCert)));
+    HIPCHK(hipMemcpyAsync(h->bC.p, h->jK.p, (size_t)Np * Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, (const double*)X, (const double*)X, rp, 0, Np, Np, rp, false, -1.0, 1.0));
+    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)h->bC.p, Np, (int)Np, (int)n,
+                       (double*)h->lrcert.p);
+    hipLaunchKernelGGL(k_jac_norm, dim3(1), dim3(1024), 0, h->stream, (const double*)h->lrcert.p, 1.0, (JacStat*)h->jstat.p);
+    HIPCHK(hipGetLastError());
     const double* src_t = (const double*)h->lrGt.p;
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));      // (sticky over the three passes: the first bad pivot counts)
     for (int pass = 0; pass < 3; ++pass) {
@@ -1606,9 +1623,15 @@ int lowrank_pinv(cgp_handle* h, long Np, long n, long r, double thresh, int* ok)
         src_t = Xt;
     }
     int info = 0;
+    JacStat est;
     CHK(d2h(h, &info, P.info, sizeof(int)));
+    CHK(d2h(h, &est, h->jstat.p, sizeof(est)));
     HIPCHK(stream_sync(h));
-    if (info != 0) return 0;
+    // (twice the bound n tol = 4 n eps dmax0 of the positive semi-definite case: what the pre-stage may lose anyway; a wrongly
+    // refused matrix only costs the time of the sweeps)
+    const double e_max = 8. * (double)n * 2.220446049250313e-16 * h->lr_dmax0;
+    if (h->env.debug) fprintf(stderr, "cgp: low-rank pre-stage: |K - G G^T|_F = %.3e (accepted up to %.3e), orthonormalisation info %d\n", est.fro, e_max, info);
+    if (info != 0 || !(est.fro <= e_max)) return 0;
     // T = Q^T K Q: KQt = Qt K (rp x Np), T = KQt Qt^T (rp x rp) into the head of jK (K is not needed after KQt)
     double* KQt = (double*)h->lrY.p;
     CHK(launch_gemm(h, 1, KQt, Np, 0, Xt, (const double*)h->jK.p, Np, 0, rp, Np, Np, false, 1.0, 0.0));
@@ -1636,6 +1659,52 @@ int lowrank_pinv(cgp_handle* h, long Np, long n, long r, double thresh, int* ok)
     return 0;
 }
 
+// Full-rank shortcut of the eigen route (jacobi.hpp, k_cert_finish): K (h->jK, left untouched) is copied, factored and
+// inverted like cgp_cholesky_inverse does; if it is positive definite, well conditioned and 1 / ||K^-1||_F clears the
+// threshold, bC = K^-1 (both triangles) IS the pseudo-inverse and jres = {log det, 0 dropped}.  *ok = 0: the caller runs
+// the sweeps (not positive definite, ill conditioned, or a mode might have to go).
+int chol_certified_pinv(cgp_handle* h, long Np, long n, double thresh, int* ok) {
+    *ok = 0;
+    const long nblk = Np / NB, ld = Np;
+    CHK(ensure(h, h->lrM, (size_t)2 * Np * Np * sizeof(double)));
+    CHK(ensure(h, h->lrws, (size_t)nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->lrldp, (size_t)nblk * sizeof(double)));
+    CHK(ensure(h, h->lrinfo, 2 * sizeof(int)));
+    CHK(ensure(h, h->lrcert, (size_t)(2 * JAC_NORM_BLOCKS) * sizeof(double) + sizeof(CholCert)));
+    Prob P;
+    P.B = 1; P.dim = 1; P.n = n; P.Np = Np; P.R = 2 * Np; P.sM = 2 * Np * Np;
+    P.M = (double*)h->lrM.p;
+    P.wsW = (double*)h->lrws.p; P.sW = nblk * 8 * 256;
+    P.ldp = (double*)h->lrldp.p; P.sLd = nblk;
+    P.info = (int*)h->lrinfo.p;
+    HIPCHK(hipMemcpyAsync(P.M, h->jK.p, (size_t)Np * Np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int), h->stream));
+    CHK(factor_range(h, P, 0, Np, 0, Np, true));
+    hipLaunchKernelGGL(k_set_identity_rows, dim3(512), dim3(256), 0, h->stream, P.M + Np * ld, ld, (int)Np);
+    HIPCHK(hipGetLastError());
+    P.tri_base = Np;                          // W = L^-T on the identity rows is upper triangular (device_inverse)
+    CHK(factor_range(h, P, 0, Np, Np, 2 * Np, false));
+    P.tri_base = -1;
+    CHK(launch_gemm(h, 1, (double*)h->bC.p, Np, 0, P.M + Np * ld, P.M + Np * ld, ld, 0, Np, Np, Np, true, 1.0, 0.0, nullptr, 0, 0, true));
+    hipLaunchKernelGGL(k_mirror_lower, dim3(512), dim3(256), 0, h->stream, (double*)h->bC.p, ld, (int)Np);
+    double* part = (double*)h->lrcert.p;
+    CholCert* cert = (CholCert*)(part + 2 * JAC_NORM_BLOCKS);
+    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)h->jK.p, ld, (int)Np, (int)n, part);
+    hipLaunchKernelGGL(k_jac_norm_partial, dim3(JAC_NORM_BLOCKS), dim3(256), 0, h->stream, (const double*)h->bC.p, ld, (int)Np, (int)n,
+                       part + JAC_NORM_BLOCKS);
+    hipLaunchKernelGGL(k_cert_finish, dim3(1), dim3(1024), 0, h->stream, (const double*)part, (const double*)(part + JAC_NORM_BLOCKS),
+                       (const double*)P.ldp, (int)nblk, (const int*)P.info, thresh, h->env.eig_cond_max, (double*)h->jres.p, cert);
+    HIPCHK(hipGetLastError());
+    CholCert c;
+    CHK(d2h(h, &c, cert, sizeof(c)));
+    HIPCHK(stream_sync(h));
+    if (h->env.debug)
+        fprintf(stderr, "cgp: eigen route, full-rank shortcut on %ld points: info %d, |K|_F %.3e, |K^-1|_F %.3e -> %s\n", n, c.info,
+                c.fro_k, c.fro_inv, c.ok ? "the inverse is the pseudo-inverse" : "sweeps");
+    *ok = c.ok;
+    return 0;
+}
+
 // Eigen route: h->jK holds the full symmetric Np x Np matrix (identity-padded, ld = Np).  Leaves the
 // pseudo-inverse (both triangles) in h->bC, logdet and the number of dropped modes in h->jres.
 int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
@@ -1645,6 +1714,8 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
     CHK(ensure(h, h->jres, 2 * sizeof(double)));
     CHK(ensure(h, h->jlam, Np * sizeof(double)));
     h->last_rank = -1;
+    h->last_route = 0;
+    h->last_sweeps = 0;
     if (n >= 256 && !h->env.jac_no_lowrank) {
         // ---- low-rank pre-stage: noise-free kernel matrices (the ones this route exists for) are numerically rank deficient
         const long rcap = std::min<long>(Np / 2, 2048);
@@ -1654,9 +1725,15 @@ int device_eig_pinv(cgp_handle* h, long Np, long n, double thresh) {
         if (r > 0 && r <= rcap) {
             int ok = 0;
             CHK(lowrank_pinv(h, Np, n, r, thresh, &ok));
-            if (ok) { h->last_rank = r; return 0; }
+            if (ok) { h->last_rank = r; h->last_route = 1; return 0; }
             // (a non-positive pivot in the orthonormalisation: the full sweeps take over, K is still in jK)
         }
+    }
+    if (n > JP && !h->env.eig_no_chol) {
+        // ---- full rank (noisy data with this route forced, svd_inverse of a well-conditioned matrix): 40 x cheaper than sweeps
+        int ok = 0;
+        CHK(chol_certified_pinv(h, Np, n, thresh, &ok));
+        if (ok) { h->last_route = 2; return 0; }
     }
     CHK(jacobi_diagonalise(h, Np, n));
     hipLaunchKernelGGL(k_jac_finish, dim3(512), dim3(256), 0, h->stream, (const double*)h->jK.p, (const double*)h->jV.p,
@@ -1774,6 +1851,12 @@ int cgp_svd_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, doub
     CHK(square_to_host(h, (double*)h->bC.p, Np, n, 0, inv_out));
     if (logdet_out) *logdet_out = res[0];
     if (n_dropped) *n_dropped = (int64_t)res[1];
+    return CGP_OK;
+}
+
+int cgp_eig_info(cgp_handle* h, int64_t out[3]) {
+    if (!h || !out) return CGP_E_ARG;
+    out[0] = h->last_route; out[1] = h->last_rank; out[2] = h->last_sweeps;
     return CGP_OK;
 }
 

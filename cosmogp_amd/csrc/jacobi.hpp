@@ -577,6 +577,33 @@ __global__ void k_pad_identity(double* __restrict__ A, long ld, int n, int Np) {
     }
 }
 
+// Full-rank shortcut of the eigen route (api.hip, chol_certified_pinv).  For a symmetric positive definite K,
+// lambda_min(K) = 1 / ||K^-1||_2 >= 1 / ||K^-1||_F: when that bound clears the threshold no singular value is dropped and the
+// pseudo-inverse IS the inverse (inv_matrix.py:7-12 keeps s > 1e-15), log det = sum of the kept log s.  The certificate also
+// asks for ||K||_F ||K^-1||_F <= cond_max, so that the computed inverse, and with it the bound, can be trusted.
+struct CholCert { double fro_k, fro_inv, logdet; int ok, info; };
+__global__ __launch_bounds__(1024) void k_cert_finish(const double* __restrict__ part_k, const double* __restrict__ part_inv,
+                                                      const double* __restrict__ ldp, int nblk, const int* __restrict__ info,
+                                                      double thresh, double cond_max, double* __restrict__ res,
+                                                      CholCert* __restrict__ out) {
+    __shared__ double red[2][16];
+    double a = part_k[threadIdx.x], b = part_inv[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0., tb = 0., lg = 0.;
+        for (int i = 0; i < 16; ++i) { ta += red[0][i]; tb += red[1][i]; }
+        for (int i = 0; i < nblk; ++i) lg += ldp[i];
+        const double fk = sqrt(ta), fi = sqrt(tb);
+        // (every comparison is false on a NaN: a failed factorisation cannot pass)
+        const int ok = info[0] == 0 && fi > 0. && fk * fi <= cond_max && 1. / fi > 100. * thresh;
+        out->fro_k = fk; out->fro_inv = fi; out->logdet = lg; out->ok = ok; out->info = info[0];
+        if (ok) { res[0] = lg; res[1] = 0.; }
+    }
+}
+
 // A (rp x rp, lower triangle from the GEMM) before a Cholesky-QR pass: the padding diagonal (indices >= r) := 1 (X has zero
 // columns there), the diagonal += shift * trace(A) over the r real indices
 __global__ __launch_bounds__(256) void k_cholqr_prepare(double* __restrict__ A, long ld, int r, int rp, double shift) {

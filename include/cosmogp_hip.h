@@ -96,6 +96,13 @@ int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
 int cgp_svd_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, double thresh,
                     double* inv_out, double* logdet_out, int64_t* n_dropped);
 
+/* Diagnostic: which way the last eigen-route call of this handle (cgp_svd_inverse, cgp_fit_svd) went.
+ *   out[0]  0 = Jacobi sweeps on the whole matrix; 1 = low-rank pre-stage (pivoted Cholesky + Rayleigh-Ritz: numerically
+ *           rank-deficient, i.e. noise-free, matrices); 2 = certified Cholesky (positive definite, well conditioned and
+ *           1 / |K^-1|_F above the threshold: no mode can be dropped, the inverse is the pseudo-inverse)
+ *   out[1]  rank found by the pre-stage (-1: none);  out[2]  outer Jacobi sweeps run (0 for route 2) */
+int cgp_eig_info(cgp_handle* h, int64_t out[3]);
+
 /* ---- fused level: one object's fit, matrices stay in HBM ---------------------------- */
 
 /* Upload one object: coordinates x (n or n x 2) and residual r = y - y0 (n doubles).

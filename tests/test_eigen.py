@@ -260,3 +260,90 @@ def test_noise_free_prediction_rank_below_and_above_the_cap(cg, ell, monkeypatch
         g2.get_prediction(new_binning=xn)
         assert np.array_equal(g2.Prediction[0], gp.Prediction[0]) and np.array_equal(g2.variance[0], gp.variance[0])
         dev2.close()
+
+
+def test_full_rank_shortcut_is_certified_and_equals_the_sweeps(cg, monkeypatch):
+    """svd_inverse of a positive definite, well-conditioned matrix (noisy data with the reference's default svd_method=True):
+    no singular value can be at or below the threshold -- certified on the device by lambda_min >= 1 / |K^-1|_F -- so the
+    pseudo-inverse is the inverse and the eigen route answers from a Cholesky factorisation (cgp_eig_info route 2) instead of
+    ~18 sweeps.  Same inverse, log-determinant and dropped count as the sweeps (CGP_EIG_NO_CHOL) and as the oracle."""
+    from cosmogp_amd import _lib
+    n = 700
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(0., 70., n))
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 4.) + np.diag(rng.uniform(0.01, 0.04, n))
+    out = {}
+    for mode in ('shortcut', 'sweeps'):
+        if mode == 'sweeps':
+            monkeypatch.setenv('CGP_EIG_NO_CHOL', '1')
+        else:
+            monkeypatch.delenv('CGP_EIG_NO_CHOL', raising=False)
+        dev = _lib.Device(0)
+        out[mode] = dev.svd_inverse(K) + (dev.eig_info(),)
+        dev.close()
+    (i2, l2, d2, r2), (i0, l0, d0, r0) = out['shortcut'], out['sweeps']
+    assert r2[0] == 2 and r2[2] == 0 and r0[0] == 0 and r0[2] > 3
+    assert d2 == d0 == 0
+    ref, ldr = orc.svd_inverse(K, return_logdet=True)
+    assert abs(l2 - l0) <= 1e-11 * abs(l0) and abs(l2 - ldr) <= 1e-11 * abs(ldr)
+    np.testing.assert_allclose(i2, i0, rtol=0, atol=1e-10 * np.abs(i0).max())       # cond ~ 4e3
+    np.testing.assert_allclose(i2, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    np.testing.assert_array_equal(i2, i2.T)
+
+
+def test_full_rank_shortcut_is_refused_when_it_cannot_be_certified(cg):
+    """The certificate must fail -- and the sweeps answer as before -- for (a) a positive definite matrix whose condition number
+    is beyond what the computed inverse can vouch for, (b) an indefinite matrix (s = |lambda|: the Cholesky factorisation stops),
+    (c) a threshold the smallest eigenvalue does not clear by the safety factor: modes may have to go."""
+    from cosmogp_amd import _lib
+    n = 300
+    rng = np.random.default_rng(11)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    dev = _lib.Device(0)
+
+    def sym(lam):
+        K = (q * lam) @ q.T
+        return 0.5 * (K + K.T)
+    # (a) cond 1e12
+    K = sym(np.logspace(0, -12, n))
+    inv, ld, nd = dev.svd_inverse(K)
+    assert dev.eig_info()[0] == 0 and nd == 0
+    assert abs(ld - np.sum(np.log(np.logspace(0, -12, n)))) <= 1e-2
+    # (b) indefinite
+    lam = np.concatenate([np.linspace(1., 3., n // 2), -np.linspace(0.5, 2., n - n // 2)])
+    K = sym(lam)
+    inv, ld, nd = dev.svd_inverse(K)
+    assert dev.eig_info()[0] == 0 and nd == 0
+    np.testing.assert_allclose(inv, sym(1. / lam), rtol=0, atol=1e-11 * np.abs(inv).max())
+    # (c) well conditioned, but the caller's threshold cuts into the spectrum
+    lam = np.logspace(0, -3, n)
+    K = sym(lam)
+    inv, ld, nd = dev.svd_inverse(K, thresh=1e-2)
+    assert dev.eig_info()[0] == 0 and nd == int(np.sum(lam <= 1e-2))
+    inv, ld, nd = dev.svd_inverse(K, thresh=1e-7)          # ... and with a threshold far below it the shortcut answers
+    assert dev.eig_info()[0] == 2 and nd == 0
+    np.testing.assert_allclose(inv, sym(1. / lam), rtol=0, atol=1e-10 * np.abs(inv).max())
+    dev.close()
+
+
+def test_forced_eigen_route_on_noisy_data_through_the_classes(cg, eigen_route):
+    """svd_method=True taken literally on noisy data of 600 points (SVD_VIA_CHOLESKY_WHEN_PD off): cgp_fit_svd, whose eigen route
+    certifies full rank on the device; prediction, covariance and likelihood against the oracle's SVD route."""
+    rng = np.random.default_rng(17)
+    n, m = 600, 50
+    x = np.sort(rng.uniform(0., 60., n))
+    e = rng.uniform(0.05, 0.15, n)
+    y = np.sin(x / 3.) + e * rng.standard_normal(n)
+    xn = np.linspace(1., 59., m)
+    dev = cg._lib.Device(0)
+    gp = cg.gaussian_process(y, x, kernel='RBF1D', y_err=e, device=dev)
+    gp.hyperparameters = [1.1, 2.5]
+    gp.get_prediction(new_binning=xn)
+    assert dev.eig_info()[0] == 2
+    want = orc.predict([y], [x], 'RBF1D', [1.1, 2.5], 0., [e], new_binning=xn, svd_method=True)
+    np.testing.assert_allclose(gp.Prediction[0], want['prediction'][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gp.covariance_matrix[0], want['covariance'][0], rtol=0, atol=1e-9)
+    gp.compute_log_likelihood([1.1, 2.5])
+    ref = orc.log_likelihood_gp(y, x, 'RBF1D', [1.1, 2.5], 0., y_err=e, y_mean=0., svd_method=True)
+    np.testing.assert_allclose(gp.log_likelihood, ref, rtol=1e-11)
+    dev.close()
