@@ -105,8 +105,8 @@ struct CgpEnv {
          dag_lead = 2, dag_dmax = 0, dag_slope = 1;
     // the same for the batched entry points (several objects per launch: the workers are never short of work, so the list
     // is lazier); at most dag_bmax objects (= leaf lanes) per launch, tile columns >= dag_batch_min_nb
-    long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 0, dag_bwindow = 2, dag_bfill = 70, dag_blead = 2, dag_bdmax = 0,
-         dag_bslope = 1, dag_border = 1;
+    long dag_batch_min_nb = 16, dag_bmax = 0, dag_bdepth = 0, dag_bwindow = 0, dag_bfill = 70, dag_blead = -1, dag_bdmax = 0,
+         dag_bslope = 1, dag_border = 1, dag_blazy = -1;
     bool no_dag_batch = false;
     void read() {
         auto num = [](const char* k, long dflt) { const char* v = getenv(k); return v ? atol(v) : dflt; };
@@ -138,9 +138,10 @@ struct CgpEnv {
         dag_batch_min_nb = num("CGP_DAG_BATCH_MIN_NB", 16);
         dag_bmax = std::max(0l, std::min(64l, num("CGP_DAG_BMAX", 0)));       // 0: by the tile count (dag_groups)
         dag_bdepth = num("CGP_DAG_BDEPTH", 0);
-        dag_bwindow = num("CGP_DAG_BWINDOW", 2);
+        dag_bwindow = num("CGP_DAG_BWINDOW", 0);             // 0 / -1 below: by the launch's work (dag_list)
         dag_bfill = num("CGP_DAG_BFILL", 70);
-        dag_blead = num("CGP_DAG_BLEAD", 2);
+        dag_blead = num("CGP_DAG_BLEAD", -1);
+        dag_blazy = num("CGP_DAG_BLAZY", -1);                 // 1 / 0: the work-bound / chain-bound schedule whatever the launch
         dag_bdmax = num("CGP_DAG_BDMAX", 0);
         dag_bslope = num("CGP_DAG_BSLOPE", 1);
         dag_border = num("CGP_DAG_BORDER", 1);
@@ -894,11 +895,25 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, bool tri, c
         // panels per far update by the tile count (tools/batch_time.py): short factorisations in small batches are still
         // chain-bound (N = 4096 x 2: 1.99 ms at depth 8, 2.23 at 16), long ones gain from depth (N = 8192 x 8: 52.7 / 50.7 /
         // 50.3 ms at 8 / 16 / 32)
-        const long auto_depth = nb < 48 ? 8 : (nb < 96 ? 16 : 32);
+        // Round 3: a launch whose bulk work dwarfs its chains (config 2: 16 x 4096 points with 1024 prediction points, config 3:
+        // 8 x 8192 with 2500, config 5: 4 x 16384) is fastest on the LAZIEST list -- only the next column kept current, one
+        // lead column, 16 / 24 panels per far update: +7 % / +4 % / +1 % on those configs --, a launch of few or small objects
+        // (chains of 58 us per step beside little work: 4096 x 2, 2048 x 16, 8192 x 2 with 64 prediction points) loses 10-60 %
+        // on it and keeps the list above (tools/r03_bscan.sh, profiles/r03_batch_schedule_scan.log).  Work per object in
+        // worker-time: tile-panel updates x 17 us; the switch sits at 4 chain times (measured: lazy wins from ~5.7, loses at ~2)
+        // and at 4 objects (three 8192-point objects with 2500 prediction points, 4.5 chain times, still lose 6 %: with few
+        // chains a critical task that waits for a worker busy on a 24-panel update is not covered by the other objects).
+        double updates = 0.;
+        sch.tri_row0 = tri ? nb + 1 : -1;
+        for (long i = 0; i < nr; ++i)
+            for (long j = sch.first(i); j < nb && j <= i; ++j) updates += (double)(j - sch.first(i));
+        const double work_us = (double)nmat * updates * sch.panel_us / (double)std::max(1, h->dag_cus - 1);
+        const bool lazy = e.dag_blazy >= 0 ? e.dag_blazy != 0 : (nmat >= 4 && work_us >= 4. * (double)nb * sch.step_us);
+        const long auto_depth = lazy ? (nb < 48 ? 16 : 24) : (nb < 48 ? 8 : (nb < 96 ? 16 : 32));
         sch.depth = e.dag_bdepth > 0 ? e.dag_bdepth : auto_depth;
         sch.dmax = e.dag_bdmax > 0 ? e.dag_bdmax : sch.depth;
-        sch.window = std::max(1l, e.dag_bwindow); sch.fill = 0.01 * e.dag_bfill;
-        sch.lead = e.dag_blead; sch.slope = e.dag_bslope;
+        sch.window = e.dag_bwindow > 0 ? e.dag_bwindow : (lazy ? 1 : 2); sch.fill = 0.01 * e.dag_bfill;
+        sch.lead = e.dag_blead >= 0 ? e.dag_blead : (lazy ? 1 : 2); sch.slope = e.dag_bslope;
     } else {
         // One object: up to 64 tile columns the chain matters most (panels per far update 8, 4 current columns); larger
         // factorisations are bulk-bound and gain from deeper, fewer updates (tools/chol_rate.py: N = 16384 53.8 -> 55.4,
@@ -909,8 +924,10 @@ int dag_list(cgp_handle* h, long nb, long nr, long nmat, bool batch, bool tri, c
         sch.dmax = e.dag_dmax > 0 ? e.dag_dmax : sch.depth;
         sch.fill = 0.01 * e.dag_fill; sch.lead = e.dag_lead; sch.slope = e.dag_slope;
     }
-    // the schedule's time budget per step is that of a whole GPU whatever the grid and the batch (an object's list must not
-    // depend on the number of objects beside it)
+    // the schedule's time budget per step is that of a whole GPU whatever the grid and the batch.  (The list of an object may
+    // differ with the number of objects beside it -- see `lazy` above --, its ARITHMETIC may not and does not: every tile
+    // receives its panels in ascending order whatever their grouping into tasks, and a task boundary is an exact store and
+    // reload of the accumulators; tests/test_dag.py compares the two lists bit for bit.)
     sch.workers = h->dag_cus - 1;
     sch.tri_row0 = tri ? nb + 1 : -1;
     const int order = batch ? (int)e.dag_border : 0;

@@ -119,7 +119,7 @@ def test_dag_c3_size(monkeypatch):
 def _batch(env, monkeypatch, xs, ys, es, xn, chunks=None):
     from cosmogp_amd import _lib
     from cosmogp_amd import kernel as K
-    for k in ('CGP_NO_DAG', 'CGP_NO_DAG_BATCH', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_DAG_GRID', 'CGP_NO_GRAPH'):
+    for k in ('CGP_NO_DAG', 'CGP_NO_DAG_BATCH', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_DAG_GRID', 'CGP_NO_GRAPH', 'CGP_DAG_BLAZY'):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -171,6 +171,41 @@ def test_dag_batch_equals_launch_route_oracle_and_any_chunking(monkeypatch):
     cut = _batch(force, monkeypatch, xs, ys, es, xn, chunks=[[0, 3, 5], [1], [2, 4, 6]])
     # (a chunk of narrower objects is padded less: same numbers to rounding there, bit-identical where the width is the same)
     assert np.array_equal(cut[0][:3], ref[0][[0, 3, 5]]) and np.array_equal(cut[2][:3], ref[2][[0, 3, 5]])
+
+
+def test_dag_batch_lazy_and_eager_schedules_bit_identical(monkeypatch):
+    """The batched route picks the task list by the launch's work (api.hip, dag_list: work-bound launches get the laziest list --
+    window 1, lead 1, 16 panels per far update --, chain-bound ones window 2, lead 2, 8 panels).  The grouping of a tile's panels
+    into tasks must not change a bit (a task boundary is an exact store and reload): six objects of 1400..1536 points (12 tile
+    columns) with 300 prediction points under both lists (CGP_DAG_BLAZY), every output compared bitwise; and the gradient /
+    leave-one-out layout likewise."""
+    rng = np.random.default_rng(15)
+    ns = [1536, 1400, 1500, 1536, 1450, 1530]
+    probs = [_problem(n, 0, 300 + i) for i, n in enumerate(ns)]
+    xs, ys, es = [p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs]
+    xn = rng.uniform(0., 40., 300)
+    force = {'CGP_DAG_BATCH_MIN_NB': '2'}
+    eager = _batch(dict(force, CGP_DAG_BLAZY='0'), monkeypatch, xs, ys, es, xn)
+    lazy = _batch(dict(force, CGP_DAG_BLAZY='1'), monkeypatch, xs, ys, es, xn)
+    auto = _batch(force, monkeypatch, xs, ys, es, xn)
+    assert not eager[1].any()
+    assert all(np.array_equal(a, b) for a, b in zip(eager, lazy))
+    assert all(np.array_equal(a, b) for a, b in zip(eager, auto))
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    kp = K.kernel_params_1d([1., 2.])
+    outs = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('CGP_DAG_BATCH_MIN_NB', '2')
+        monkeypatch.setenv('CGP_DAG_BLAZY', flag)
+        dev = _lib.Device(0)
+        dev.batch_fit(1, xs, ys, [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)], kp, None, None, 0.)
+        g = dev.batch_fit_grad_resident(kp)
+        loo = dev.batch_loo(kp)
+        # (entries of the leave-one-out arrays beyond an object's own length are undefined)
+        outs.append([np.asarray(v) for v in g] + [np.concatenate([loo[q][i, :ns[i]] for i in range(len(ns))]) for q in range(3)] + [loo[3]])
+        dev.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
 
 
 def test_dag_batch_reports_the_failing_object(monkeypatch):

@@ -29,8 +29,9 @@ def run_stress(budget, seed=1, sizes=(130, 257, 400, 640, 900, 1300, 2050, 2600,
       outs = []
       single = B == 1 and rng.random() < 0.5
       bmax = str(int(rng.integers(1, 5))) if rng.random() < 0.3 else ''
+      blazy = rng.choice(['', '0', '1'])           # task list of the batched route: by the launch's work / eager / lazy
       for route in ('dag', 'steps'):
-          for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_MIN_NB', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX'):
+          for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_MIN_NB', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_DAG_BLAZY'):
               os.environ.pop(k, None)
           if route == 'steps':
               os.environ['CGP_NO_DAG'] = '1'
@@ -40,6 +41,8 @@ def run_stress(budget, seed=1, sizes=(130, 257, 400, 640, 900, 1300, 2050, 2600,
                   os.environ['CGP_DAG_GRID'] = grid
               if bmax:
                   os.environ['CGP_DAG_BMAX'] = bmax
+              if blazy:
+                  os.environ['CGP_DAG_BLAZY'] = blazy
           dev = _lib.Device(0)
           diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
           if single:
@@ -66,7 +69,7 @@ def run_stress(budget, seed=1, sizes=(130, 257, 400, 640, 900, 1300, 2050, 2600,
       if err > 1e-9 or err2 > 1e-5:
           n_bad += 1
           if verbose: print('MISMATCH n=%d B=%d m=%d grid=%r: %.2e %.2e' % (n, B, m, grid, err, err2), flush=True)
-  for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_MIN_NB', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX'):
+  for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_DAG_MIN_NB', 'CGP_DAG_BATCH_MIN_NB', 'CGP_DAG_BMAX', 'CGP_DAG_BLAZY'):
       os.environ.pop(k, None)
   return n_cases, n_bad, worst
 
