@@ -81,6 +81,8 @@ struct Prob {
     // tri_base + c.
     long wrow0 = -1, zrow = -1, tri_base = -1;
     int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
+    int gen_on = 0;      // 1 / 2: first-touch generation active for this factorisation (kernels.hpp, GenSrc), coordinates of 1 / 2 components
+    GenSrc gen;
     bool batch_api = false;   // bound by a batched entry point: always the launch-per-step route, whatever B, so that an object's
                               // numbers do not depend on how a caller chunks its batches (the single-launch route of cgp_fit
                               // associates the sums differently: same result to rounding, not bit for bit)
@@ -98,7 +100,7 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0, eig_cond_max = 1e10;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -123,6 +125,7 @@ struct CgpEnv {
         jac_no_small = getenv("CGP_JAC_NO_SMALL") != nullptr;
         jac_no_lowrank = getenv("CGP_JAC_NO_LOWRANK") != nullptr;
         eig_no_chol = getenv("CGP_EIG_NO_CHOL") != nullptr;
+        no_fused_asm = getenv("CGP_NO_FUSED_ASM") != nullptr;
         if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
@@ -408,6 +411,11 @@ int leaf_attr_once(cgp_handle* h) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_trsm_panel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        const void* gen_fns[] = {(const void*)k_potrf_diag_gen<1>, (const void*)k_potrf_diag_gen<2>,
+                                 (const void*)k_trsm_panel<4, 1>, (const void*)k_trsm_panel<4, 2>, (const void*)k_trsm_panel<8, 1>,
+                                 (const void*)k_trsm_panel<8, 2>, (const void*)k_trsm_panel<16, 1>, (const void*)k_trsm_panel<16, 2>};
+        for (const void* f : gen_fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
         err_dev[d] = e;
     });
     HIPCHK(err_dev[d]);
@@ -418,7 +426,8 @@ int leaf_attr_once(cgp_handle* h) {
 // the region are lower-triangular (tile granularity), the rest full.
 int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
                 long ld, long sAB, long rows, long cols, long K, bool tri, double alpha, double beta,
-                hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false) {
+                hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false,
+                const GenSrc* gen = nullptr, int gen_dim = 0) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
     if (bulk_cap == 0 && B == 1 && tile_skip == 0 && !ktri && h->env.bulk_cap > 0 && rows % 128 == 0 && cols % 128 == 0) {
@@ -433,6 +442,7 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
     // whatever the tile count, tools/batch_time.py with CGP_BIGTILE).  Both forms sum in the same order: same bits.
     const bool big_form = bulk_cap == 0 && rows % 128 == 0 &&
         tiles_big_ * B >= h->env.bigtile && (rows >= 2048 || cols >= 2048);
+    if (gen && (big_form || bulk_cap > 0 || beta != 1.0)) return fail(h, CGP_E_STATE, "first-touch generation asked of a large update form");
     StageScope sc(h, big_form ? ST_GEMM_BIG : ST_GEMM);
     h->gemm_launches++;
     {   // algorithmic flops: 2 K per C element actually needed (lower triangle incl. diagonal when tri)
@@ -481,6 +491,13 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         if (tiles <= 0) return 0;
         {
         dim3 g((unsigned)tiles, 1, (unsigned)B);
+        if (gen && gen_dim == 1)
+            hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 1>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, *gen);
+        else if (gen)
+            hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 2>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, *gen);
+        else
         hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
                            (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0);
         }
@@ -505,6 +522,16 @@ hipEvent_t next_fork_event(cgp_handle* h) {
 
 int launch_potrf(cgp_handle* h, Prob& P, long c0, hipStream_t stream) {
     StageScope sc(h, ST_POTRF);
+    if (P.gen_on && c0 == 0) {
+        GenSrc g = P.gen;
+        g.row0 = 0; g.col0 = 0;
+        if (P.gen_on == 1)
+            hipLaunchKernelGGL(k_potrf_diag_gen<1>, dim3(1, 1, P.B), dim3(CGP_K3_THREADS), LEAF_LDS, stream, P.M, P.Np, P.sM, (int)c0,
+                               P.wsW, P.sW, P.ldp, P.sLd, P.info, (int)(c0 / NB), g);
+        else
+            hipLaunchKernelGGL(k_potrf_diag_gen<2>, dim3(1, 1, P.B), dim3(CGP_K3_THREADS), LEAF_LDS, stream, P.M, P.Np, P.sM, (int)c0,
+                               P.wsW, P.sW, P.ldp, P.sLd, P.info, (int)(c0 / NB), g);
+    } else
     hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, P.B), dim3(CGP_K3_THREADS), LEAF_LDS, stream, P.M, P.Np, P.sM, (int)c0,
                        P.wsW, P.sW, P.ldp, P.sLd, P.info, (int)(c0 / NB));
     HIPCHK(hipGetLastError());
@@ -577,12 +604,12 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             // costs less than the twice as many 4-wave workgroups each staging L_kk for itself)
             if (rows % 64 != 0 || (w == 16 && rows % 256 != 0)) w = 4;
             const dim3 g((unsigned)((rows + 16 * w - 1) / (16 * w)), 1, P.B);
-            if (w == 4)
-                hipLaunchKernelGGL(k_trsm_panel<4>, g, dim3(256), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
-            else if (w == 8)
-                hipLaunchKernelGGL(k_trsm_panel<8>, g, dim3(512), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
-            else
-                hipLaunchKernelGGL(k_trsm_panel<16>, g, dim3(1024), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows);
+            const int gen = (P.gen_on && chol && c0 == 0) ? P.gen_on : 0;       // first touch of the rows below block (0, 0)
+#define CGP_TRSM_LAUNCH(W, G) hipLaunchKernelGGL((k_trsm_panel<W, G>), g, dim3(64 * W), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows, P.gen)
+            if (w == 4) { if (gen == 1) CGP_TRSM_LAUNCH(4, 1); else if (gen == 2) CGP_TRSM_LAUNCH(4, 2); else CGP_TRSM_LAUNCH(4, 0); }
+            else if (w == 8) { if (gen == 1) CGP_TRSM_LAUNCH(8, 1); else if (gen == 2) CGP_TRSM_LAUNCH(8, 2); else CGP_TRSM_LAUNCH(8, 0); }
+            else { if (gen == 1) CGP_TRSM_LAUNCH(16, 1); else if (gen == 2) CGP_TRSM_LAUNCH(16, 2); else CGP_TRSM_LAUNCH(16, 0); }
+#undef CGP_TRSM_LAUNCH
             HIPCHK(hipGetLastError());
         }
         return 0;                                // leaf kernels run on the main stream in order: no mark needed
@@ -600,6 +627,13 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
     }
     const long rs = chol ? mid : rlo;
     if (chol) CHK(dep_wait(h, S, mid / NB, c1 / NB));
+    if (P.gen_on && chol && c0 == 0) {
+        // the one update launch that touches block columns [mid, c1) first: its "C" is computed (kernels.hpp, GenSrc)
+        GenSrc g = P.gen;
+        g.row0 = (int)rs; g.col0 = (int)mid;
+        CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
+                        P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S, 0, 0, false, &g, P.gen_on));
+    } else
     CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
                     P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
     return factor_range(h, P, mid, c1, rlo, R, chol);
@@ -1075,6 +1109,19 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
     // device-only part of a fit: everything already in HBM (cgp_fit, cgp_batch_fit, cgp_bench_fit)
     const long ld = P.Np, Mp = P.R - P.Np;
     HIPCHK(hipMemsetAsync(P.info, 0, sizeof(int) * P.B, h->stream));
+    // Small objects on the launch-per-step route with the small update tiles: no assembly launches, the kernels that touch a
+    // tile first compute it (kernels.hpp, GenSrc; config 4: 388k -> fits/s)
+    const bool to_dag = dag_eligible(h, P) && !h->trk.active;
+    const bool fuse = !to_dag && !h->trk.active && P.R < 2048 && P.tri_base < 0 && !h->env.no_fused_asm && h->env.bulk_cap == 0 &&
+                      P.wrow0 < 0 && P.zrow < 0;
+    P.gen_on = 0;
+    if (fuse) {
+        P.gen_on = P.dim == 2 ? 2 : 1;
+        GenSrc& g = P.gen;
+        g.x = P.x; g.sx = P.sx; g.xnew = P.xnew ? P.xnew : P.x; g.sxn = P.xnew ? P.sxn : 0; g.diag = P.diag; g.sd = P.sd;
+        g.resid = P.r; g.sr = P.sr; g.ns = P.ns; g.kpp = (const KParams*)h->bkp.p; g.kps = P.kps;
+        g.m = (int)m; g.Np = (int)P.Np; g.zrow = (int)P.zr();
+    } else {
     {
         StageScope sc(h, ST_ASM_K);
         CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true, P.kps));
@@ -1086,6 +1133,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
                                   m, P.kps));
         CHK(put_resid_row(h, P));
     }
+    }
     if (h->trk.active) {
         h->trk.last.assign(P.Np / NB, nullptr);
         h->trk.owner.assign(P.Np / NB, nullptr);
@@ -1094,8 +1142,12 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         HIPCHK(hipEventRecord(e0, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
     }
-    if (dag_eligible(h, P) && !h->trk.active) CHK(launch_dag(h, P));
-    else CHK(factor_range(h, P, 0, P.Np, 0, P.R, true));
+    if (to_dag) CHK(launch_dag(h, P));
+    else {
+        const int st = factor_range(h, P, 0, P.Np, 0, P.R, true);
+        P.gen_on = 0;
+        CHK(st);
+    }
     if (h->trk.active) {
         // join: everything the second stream did must be complete before the finish kernel (and the
         // capture can only end once every forked stream has been joined)

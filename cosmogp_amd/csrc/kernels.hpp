@@ -273,6 +273,69 @@ __global__ void k_pad_square(const double* __restrict__ src, long lds, double* _
 }
 
 // ------------------------------------------------------------------------------------
+// First-touch generation (round 3; objects whose whole fit runs on the launch-per-step route with the small update tiles:
+// R < 2048, config 4).  A fit of such an object is HBM-bound -- 8.9 MB of traffic for 0.07 Gflop at N = 512 -- and 3.1 MB of
+// it is the assembled matrix written by K1 / K2 and read back by whichever kernel touches a tile first.  Those kernels are
+// known: tile (0, 0) is first read by the factorisation of block column 0, the rest of block column 0 by its panel solve,
+// every other block column by the ONE update launch with c0 = 0 that covers it (factor_range's left spine).  With GEN != 0
+// they compute the entry instead of loading it (the same device functions as K1 / K2, operation by operation: same bits),
+// and the assembly launches disappear.  GEN = 1 / 2: coordinates of 1 / 2 components.
+//   rows < Np: train rows (index >= n: identity padding); Np + t, t < m: cross row of new point t; zrow: the residual;
+//   every other tall row: zeros.
+// ------------------------------------------------------------------------------------
+struct GenSrc {
+    const double* x = nullptr; long sx = 0;
+    const double* xnew = nullptr; long sxn = 0;
+    const double* diag = nullptr; long sd = 0;
+    const double* resid = nullptr; long sr = 0;
+    const int* ns = nullptr;
+    const KParams* kpp = nullptr; int kps = 0;
+    int m = 0, Np = 0, zrow = 0;
+    int row0 = 0, col0 = 0;          // absolute (row, column) of the origin of the launch's region
+};
+struct GenObj { const double* x; const double* xnew; const double* diag; const double* resid; KParams kp; double yinv; int n; bool dvi; };
+struct GenRow { double vx, vy, dg; int kind; };      // kind 0 train row, 1 identity padding, 2 cross row, 3 zero row, 4 residual
+
+template <int DIM>
+__device__ __forceinline__ GenObj gen_obj(const GenSrc& g, int b) {
+    GenObj o;
+    o.x = g.x + (long)b * g.sx; o.xnew = g.xnew + (long)b * g.sxn; o.diag = g.diag + (long)b * g.sd; o.resid = g.resid + (long)b * g.sr;
+    o.kp = g.kpp[(long)b * g.kps];
+    o.yinv = rbf_arg_const<DIM>(o.kp);
+    o.n = g.ns[b];
+    o.dvi = DIM == 2 && o.kp.p1 == 0. && o.kp.p2 == 0.;
+    return o;
+}
+template <int DIM>
+__device__ __forceinline__ GenRow gen_row(const GenSrc& g, const GenObj& o, int i) {
+    GenRow r;
+    r.vx = 0.; r.vy = 0.; r.dg = 0.;
+    if (i < g.Np) {
+        r.kind = i < o.n ? 0 : 1;
+        r.vx = o.x[(long)i * DIM];
+        if (DIM == 2) r.vy = o.x[(long)i * DIM + 1];
+        if (i < o.n) r.dg = o.kp.amp_train + (o.diag[i] + o.kp.nug2);
+    } else if (i - g.Np < g.m) {
+        r.kind = 2;
+        r.vx = o.xnew[(long)(i - g.Np) * DIM];
+        if (DIM == 2) r.vy = o.xnew[(long)(i - g.Np) * DIM + 1];
+    } else r.kind = i == g.zrow ? 4 : 3;
+    return r;
+}
+// entry (i, c) of the object's assembled matrix; (ux, uy) = the point of column c
+template <int DIM>
+__device__ __forceinline__ double gen_val(const GenObj& o, const GenRow& r, int i, int c, double ux, double uy, const double* etab) {
+#pragma clang fp contract(off)
+    if (r.kind == 1) return c == i ? 1. : 0.;
+    if (r.kind == 3) return 0.;
+    if (r.kind == 4) return c < o.n ? o.resid[c] : 0.;
+    const double a = o.dvi ? rbf_exp_arg<DIM, true>(ux, uy, r.vx, r.vy, o.kp, o.yinv) : rbf_exp_arg<DIM, false>(ux, uy, r.vx, r.vy, o.kp, o.yinv);
+    const double e = (r.kind == 0 ? o.kp.amp_train : o.kp.amp_cross) * rbf_exp(a, etab);
+    if (c >= o.n) return 0.;
+    return (r.kind == 0 && c == i) ? r.dg : e;
+}
+
+// ------------------------------------------------------------------------------------
 // K3: Cholesky of one NB x NB diagonal block, entirely in LDS, one workgroup (4 waves).
 //   8 sub-steps of 16 columns:
 //   (a) wave 0 factors the 16 x 16 diagonal sub-block T in registers: lane r < 16 owns row r;
@@ -467,9 +530,10 @@ __device__ __forceinline__ int potrf128_lds(double* As, double* Ws, double* Lc) 
     return bad;
 }
 
-__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
+template <int GEN>
+__device__ __forceinline__ void potrf_diag_body(
     double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
-    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk) {
+    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk, const GenSrc& g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem;                          // [128][CGP_LDA]
     double* Ws = smem + CGP_NB * CGP_LDA;       // [8][16][16]  T^-T blocks (upper triangular)
@@ -480,6 +544,37 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     CGP_STAMP(0);
+    if (GEN != 0) {
+        // first touch of this block: its entries are computed (see GenSrc), sub-tiles on and below the block diagonal
+        constexpr int GD = GEN == 2 ? 2 : 1;
+        __shared__ __attribute__((aligned(16))) double etab[128];
+        rbf_stage_table(etab);
+        const GenObj o = gen_obj<GD>(g, b);
+        // a thread's column pair is the same in every pass and the row is the same for the whole wave: the column points are
+        // loaded once, the 128 row descriptors go through LDS (Ws is free until the factorisation starts): no global load
+        // inside the loop
+        GenRow* rws = (GenRow*)Ws;                           // 128 x 32 B = 4 KB of the 16 KB
+        if (tid < CGP_NB) rws[tid] = gen_row<GD>(g, o, g.row0 + tid);
+        const int c = (tid & 63) * 2, cc = g.col0 + c;
+        double ux0, uy0 = 0., ux1, uy1 = 0.;
+        if (GD == 1) { const d2 t = *(const d2*)(o.x + cc); ux0 = t.x; ux1 = t.y; }
+        else { const d2 t0 = *(const d2*)(o.x + 2 * (long)cc), t1 = *(const d2*)(o.x + 2 * (long)cc + 2); ux0 = t0.x; uy0 = t0.y; ux1 = t1.x; uy1 = t1.y; }
+        __syncthreads();
+        constexpr int NCH = CGP_NB * (CGP_NB / 2) / CGP_K3_THREADS;
+#pragma unroll 4
+        for (int k = 0; k < NCH; ++k) {
+            // (computed for every lane, stored for the sub-tiles on and below the diagonal: no branch around the arithmetic, so
+            // the unrolled passes interleave -- the dependent fp64 chain of one entry is ~25 operations of 30-40 cycles each)
+            const int r = (tid >> 6) + k * (CGP_K3_THREADS / 64);
+            const int i = g.row0 + r;
+            const GenRow rw = rws[r];
+            d2 v;
+            v.x = gen_val<GD>(o, rw, i, cc, ux0, uy0, etab);
+            v.y = gen_val<GD>(o, rw, i, cc + 1, ux1, uy1, etab);
+            if ((c >> 4) <= (r >> 4)) *(d2*)(As + r * CGP_LDA + c) = v;
+        }
+        __syncthreads();
+    } else {
     // load the block by direct global -> LDS loads: one wave instruction = one full row (128 doubles) into
     // As[r][0..127]; the part right of the diagonal tile is never read
     for (int r = wave; r < CGP_NB; r += CGP_K3_THREADS / 64)
@@ -487,6 +582,7 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
                                          (__attribute__((address_space(3))) void*)(As + r * CGP_LDA), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }
     CGP_STAMP(1);
 
     const int bad = potrf128_lds(As, Ws, Lc);
@@ -516,6 +612,19 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
     CGP_STAMP(41);
 }
 
+__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
+    double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
+    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk) {
+    potrf_diag_body<0>(M, ld, sM, c0, wsW, sW, logdet_parts, sLd, info, blk, GenSrc());
+}
+// the same with the block's entries computed instead of loaded (first touch, see GenSrc); GEN = 1 / 2
+template <int GEN>
+__global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag_gen(
+    double* __restrict__ M, long ld, long sM, int c0, double* __restrict__ wsW, long sW,
+    double* __restrict__ logdet_parts, long sLd, int* __restrict__ info, int blk, GenSrc g) {
+    potrf_diag_body<GEN>(M, ld, sM, c0, wsW, sW, logdet_parts, sLd, info, blk, g);
+}
+
 // ------------------------------------------------------------------------------------
 // K4: panel solve  X = A L_kk^-T  for the rows below a diagonal block (right-looking over the
 // eight 16-column tiles): X_j = S_j T_j^-T, then S_i -= X_j L_ij^T for i > j.
@@ -524,10 +633,10 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag(
 // L_kk (strictly lower 16x16 tiles) and the T_j^-T blocks are staged in LDS once per workgroup.
 // ------------------------------------------------------------------------------------
 
-template <int K4W>
+template <int K4W, int GEN = 0>
 __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
-    long sW, int blk, int nrows) {
+    long sW, int blk, int nrows, GenSrc g = GenSrc()) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ls = smem;                               // [128][CGP_LDA] strictly-lower tiles used
     double* Ws = smem + CGP_NB * CGP_LDA;            // [8][16][16]
@@ -551,7 +660,7 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     // tile stands for column 4 u + J (any fixed permutation is legal as long as the B operands use
     // the same one), so a lane's four J values are 4 contiguous doubles: 16-byte loads/stores.
     double S[8][4];
-    if (has_rows) {
+    if (GEN == 0 && has_rows) {
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
             d2 t0 = *(const d2*)(Ap + jb * 16), t1 = *(const d2*)(Ap + jb * 16 + 2);
@@ -571,6 +680,30 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
         for (int k = 0; k < 1024 / K4T; ++k) w[k] = *(const d2*)(wsW + 2 * (tid + k * K4T));
 #pragma unroll
         for (int k = 0; k < 1024 / K4T; ++k) *(d2*)(Ws + 2 * (tid + k * K4T)) = w[k];
+    }
+    if (GEN != 0) {
+        // first touch of these rows (panel 0): computed, not loaded (see GenSrc), while the loads of L_kk above are in flight
+        constexpr int GD = GEN == 2 ? 2 : 1;
+        __shared__ __attribute__((aligned(16))) double etab[128];
+        rbf_stage_table(etab);
+        __syncthreads();
+        if (has_rows) {
+            const GenObj o = gen_obj<GD>(g, b);
+            const int i = r0 + blockIdx.x * (16 * K4W) + wave * 16 + 4 * lb + lq;
+            const GenRow rw = gen_row<GD>(g, o, i);
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const int cc = c0 + jb * 16 + 4 * lu;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    double ux0, uy0 = 0., ux1, uy1 = 0.;
+                    if (GD == 1) { const d2 t = *(const d2*)(o.x + cc + e); ux0 = t.x; ux1 = t.y; }
+                    else { const d2 t0 = *(const d2*)(o.x + 2 * (long)(cc + e)), t1 = *(const d2*)(o.x + 2 * (long)(cc + e) + 2); ux0 = t0.x; uy0 = t0.y; ux1 = t1.x; uy1 = t1.y; }
+                    S[jb][e] = gen_val<GD>(o, rw, i, cc + e, ux0, uy0, etab);
+                    S[jb][e + 1] = gen_val<GD>(o, rw, i, cc + e + 1, ux1, uy1, etab);
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -642,14 +775,15 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
 //   tri = 1: only tiles on/below the diagonal of the (square-tiled) C region are launched:
 //   tile rows [0, nc) form the triangle, rows [nc, nr) are full.
 // ------------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN> struct MT_OK_FOR_GEN { static constexpr bool value = (TM / WM / 16) * (TN / WN / 4) <= 8; };
 // KB = stage depth (16 or 32); LDS row stride KB + 2 doubles keeps every row 16-B aligned
 // ABLATE (diagnostic builds only, tools/gemm_ablate.hip): 1 = no global loads inside the loop,
 // 2 = additionally no LDS fragment reads inside the loop (wrong results, timing only)
-template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0>
+template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0, int GEN = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
-    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0) {
+    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc()) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -664,6 +798,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     C += (long)bz * sC;
     A += (long)bz * sAB;
     B += (long)bz * sAB;
+    // GEN (small wave tiles only): the update is the first touch of its C region -- the "beta C" term is computed (GenSrc)
+    constexpr int GD = GEN == 2 ? 2 : 1;
+    static_assert(GEN == 0 || MT_OK_FOR_GEN<TM, TN, WM, WN>::value, "GEN needs the early-C form");
+    __shared__ __attribute__((aligned(16))) double etab[GEN != 0 ? 128 : 2];
+    if (GEN != 0) {
+        rbf_stage_table(etab);
+        __syncthreads();
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -734,7 +876,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     // latency of the epilogue hides under it (8 more registers; the large form keeps its 4 waves per SIMD instead)
     constexpr bool EARLYC = (MT * NJ <= 8);
     double cv[EARLYC ? MT : 1][EARLYC ? NJ : 1];
-    if (EARLYC && beta != 0.) {
+    if (GEN != 0) {
+        // (computed below, once the first two stage loads are on their way)
+    } else if (EARLYC && beta != 0.) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -797,6 +941,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     gload(P0{}, 0);
     gload(P1{}, 1);
     __builtin_amdgcn_sched_barrier(0);      // keep the loads where they are written (see above)
+    if (GEN != 0) {
+        const GenObj o = gen_obj<GD>(g, bz);
+        const int rr0 = g.row0 + ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq, cc0 = g.col0 + tj * TN + wn * (TN / WN) + lp;
+        double ux[NJ], uy[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            ux[j] = o.x[(long)(cc0 + 4 * j) * GD];
+            uy[j] = GD == 2 ? o.x[(long)(cc0 + 4 * j) * GD + 1] : 0.;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const GenRow rw = gen_row<GD>(g, o, rr0 + 16 * i);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                cv[EARLYC ? i : 0][EARLYC ? j : 0] = gen_val<GD>(o, rw, rr0 + 16 * i, cc0 + 4 * j, ux[j], uy[j], etab);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     lstore(P0{}, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {

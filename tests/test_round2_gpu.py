@@ -409,3 +409,46 @@ def test_in_place_edits_of_the_data_are_noticed():
     gp.get_prediction(new_binning=xn, svd_method=False)
     want = fresh(y[::-1], x, 2. * e)
     assert np.array_equal(gp.Prediction[0], want[0])
+
+
+@pytest.mark.parametrize('dim', [1, 2])
+def test_first_touch_generation_bit_identical_to_assembled(dim, monkeypatch):
+    """Small objects (R < 2048, launch-per-step route): the assembly launches are gone, the kernels that touch a tile first
+    compute its entries (csrc/kernels.hpp, GenSrc).  Same device functions, operation by operation: every output of a batched fit
+    -- ragged lengths 130..700 (identity padding, partial last tiles), prediction points, a mean, hyper-parameter sweep with one
+    parameter set per candidate -- must equal the assembled route (CGP_NO_FUSED_ASM=1) bit for bit."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(40 + dim)
+    ns = [700, 130, 512, 640, 385, 257]
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 37)
+        kp = K.kernel_params_1d([0.9, 2.5], 0.03)
+        kps = [K.kernel_params_1d([s_, l_], 0.03) for s_, l_ in ((0.7, 2.0), (1.1, 3.0), (0.9, 1.5))]
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (37, 2))
+        kp = K.kernel_params_2d([0.9, 4.0, 5.0, 3.0], nugget=0.03)
+        kps = [K.kernel_params_2d(h_, sigma2_in_train=True, nugget=0.03) for h_ in ([0.7, 4., 4., 0.], [1.1, 5., 3., 2.], [0.9, 3., 6., 0.])]
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    outs = []
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('CGP_NO_FUSED_ASM', flag)
+        else:
+            monkeypatch.delenv('CGP_NO_FUSED_ASM', raising=False)
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, np.full(len(xn), 0.25), 0.01)
+        r2 = dev.batch_fit(dim, xs[:2], ys[:2], diags[:2], kp, None, None, 0.)          # log-likelihood only
+        dev.set_data(dim, xs[0], ys[0])
+        one = dev.fit(kp, diags[0], xn, None, 0.)
+        sweep = dev.sweep_loglik(np.array(kps), diags[0])
+        outs.append([r[0], r[1], r[2], r[3], r2[0], np.array([one[0], one[1]]), one[2], one[3], np.asarray(sweep[0])])
+        dev.close()
+    assert not outs[0][1].any()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
