@@ -599,10 +599,14 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             const int force = h->env.k4_waves;
             int w = 4;
             if (force) w = force;
+            // (batches of small objects: 16 waves = 256 rows per workgroup as long as that still leaves half the chip's worth of
+            // workgroups -- L_kk is staged once per 256 rows and four waves per SIMD cover the solve's latency; the last
+            // workgroup of an object may be part empty (nrows): config 4 416k -> 436k fits/s)
+            else if ((long)P.B * ((rows + 255) / 256) >= cus / 2) w = 16;
             else if ((rows / 64) * P.B > cus) w = ((rows / 128) * P.B > cus && rows % 256 == 0) ? 16 : 8;
             // (rows is a multiple of 64; with 8 waves the last workgroup of an odd number of 64-row groups is half full, which
             // costs less than the twice as many 4-wave workgroups each staging L_kk for itself)
-            if (rows % 64 != 0 || (w == 16 && rows % 256 != 0)) w = 4;
+            if (rows % 64 != 0) w = 4;
             const dim3 g((unsigned)((rows + 16 * w - 1) / (16 * w)), 1, P.B);
             const int gen = (P.gen_on && chol && c0 == 0) ? P.gen_on : 0;       // first touch of the rows below block (0, 0)
 #define CGP_TRSM_LAUNCH(W, G) hipLaunchKernelGGL((k_trsm_panel<W, G>), g, dim3(64 * W), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows, P.gen)
