@@ -452,3 +452,18 @@ def test_first_touch_generation_bit_identical_to_assembled(dim, monkeypatch):
     assert not outs[0][1].any()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_first_touch_generation_randomised_subset(monkeypatch):
+    """A seeded ~6-s pass of tools/fused_stress.py: random dimension / sizes 3..1900 / batch 1..64 / prediction points 0..400 /
+    mean / hyper-parameters (lxy = 0 and != 0, nugget, sigma^2 in the 2D train matrix or not), cgp_fit and cgp_batch_fit with
+    first-touch generation against the assembly launches, bit for bit."""
+    import importlib.util
+    import os
+    monkeypatch.delenv('CGP_NO_FUSED_ASM', raising=False)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fused_stress.py')
+    spec = importlib.util.spec_from_file_location('cgp_tool_fused_stress', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases, bad = mod.run_fused_stress(6., seed=20264)
+    assert cases >= 30 and bad == 0, (cases, bad)
