@@ -41,6 +41,18 @@ SPEC_FP64_MFMA_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (AMD
 SPEC_HBM_GBS = 8000.0
 
 
+def kernel_source_hash():
+    """sha256 over the device sources of the library: the PMC traffic files under profiles/ record it at collection time
+    (tools/pmc_traffic.py, tools/pmc_pass_traffic.py), and the bench line says whether the replayed constant still belongs to
+    the code that ran (`roofline.traffic_source_current`; tests/test_host_logic.py checks the default workload's file)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp', 'api.hip'):
+        with open(os.path.join(ROOT, 'cosmogp_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def make_workload(name, rank=0, obj=0, nobj=128):
     from cosmogp_amd import kernel as K
     if name == 'c3':

@@ -100,7 +100,7 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0, eig_cond_max = 1e10;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -126,6 +126,7 @@ struct CgpEnv {
         jac_no_lowrank = getenv("CGP_JAC_NO_LOWRANK") != nullptr;
         eig_no_chol = getenv("CGP_EIG_NO_CHOL") != nullptr;
         no_fused_asm = getenv("CGP_NO_FUSED_ASM") != nullptr;
+        no_xcd = getenv("CGP_NO_XCD") != nullptr;
         if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
@@ -422,6 +423,13 @@ int leaf_attr_once(cgp_handle* h) {
     return 0;
 }
 
+// Object count handed to the XCD-affine mapping of a batched launch (0 = plain grid): batches of at least 16 objects with
+// more than one workgroup per object (with one there is nothing to share) and a grid the padding fits (CGP_NO_XCD=1: off)
+int xcd_objects(cgp_handle* h, long B, long groups_per_object) {
+    if (h->env.no_xcd || B < 16 || groups_per_object < 2 || round_up(B, 8) > 65535) return 0;
+    return (int)B;
+}
+
 // C[rows x cols] = beta C + alpha A B^T ; rows/cols multiples of 128.  tri: rows [0, cols) of
 // the region are lower-triangular (tile granularity), the rest full.
 int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
@@ -490,16 +498,19 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const long tiles = (tri ? nc * (nc + 1) / 2 + (nr - nc) * nc : nr * nc) - tile_skip;
         if (tiles <= 0) return 0;
         {
-        dim3 g((unsigned)tiles, 1, (unsigned)B);
+        // batches of small objects: all tiles of an object on ONE XCD (kernels.hpp, xcd_affine), object count padded to 8
+        const int xb = xcd_objects(h, B, tiles);
+        dim3 g((unsigned)tiles, 1, (unsigned)(xb ? round_up(B, 8) : B));
+        const GenSrc g0 = gen ? *gen : GenSrc();
         if (gen && gen_dim == 1)
             hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 1>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, *gen);
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
         else if (gen)
             hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 2>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, *gen);
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
         else
         hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0);
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
         }
     }
     HIPCHK(hipGetLastError());
@@ -607,9 +618,11 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             // (rows is a multiple of 64; with 8 waves the last workgroup of an odd number of 64-row groups is half full, which
             // costs less than the twice as many 4-wave workgroups each staging L_kk for itself)
             if (rows % 64 != 0) w = 4;
-            const dim3 g((unsigned)((rows + 16 * w - 1) / (16 * w)), 1, P.B);
+            const long groups = (rows + 16 * w - 1) / (16 * w);
+            const int xb = xcd_objects(h, P.B, groups);               // the workgroups of an object share L_kk: one XCD (xcd_affine)
+            const dim3 g((unsigned)groups, 1, (unsigned)(xb ? round_up(P.B, 8) : P.B));
             const int gen = (P.gen_on && chol && c0 == 0) ? P.gen_on : 0;       // first touch of the rows below block (0, 0)
-#define CGP_TRSM_LAUNCH(W, G) hipLaunchKernelGGL((k_trsm_panel<W, G>), g, dim3(64 * W), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows, P.gen)
+#define CGP_TRSM_LAUNCH(W, G) hipLaunchKernelGGL((k_trsm_panel<W, G>), g, dim3(64 * W), LEAF_LDS, S, P.M, ld, P.sM, (int)c0, (int)r0, P.wsW, P.sW, blk, (int)rows, P.gen, xb)
             if (w == 4) { if (gen == 1) CGP_TRSM_LAUNCH(4, 1); else if (gen == 2) CGP_TRSM_LAUNCH(4, 2); else CGP_TRSM_LAUNCH(4, 0); }
             else if (w == 8) { if (gen == 1) CGP_TRSM_LAUNCH(8, 1); else if (gen == 2) CGP_TRSM_LAUNCH(8, 2); else CGP_TRSM_LAUNCH(8, 0); }
             else { if (gen == 1) CGP_TRSM_LAUNCH(16, 1); else if (gen == 2) CGP_TRSM_LAUNCH(16, 2); else CGP_TRSM_LAUNCH(16, 0); }

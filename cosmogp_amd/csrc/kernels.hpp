@@ -28,7 +28,7 @@ __device__ unsigned long long g_stamps[256];
 #define CGP_STAMP(i) do {} while (0)
 #endif
 
-struct KParams {            // mirrors the 6-double "kp" of include/cosmogp_hip.h ...
+struct KParams {            // mirrors the 7-double "kp" of include/cosmogp_hip.h ...
     double amp_train, amp_cross, p0, p1, p2, p3;
     double nug2;            // added to every element of the resident diagonal vector: the nugget**2 term
                             // of (y_err**2 + floor**2) + nugget**2 (kernel.py:75), so that a new nugget
@@ -336,6 +336,26 @@ __device__ __forceinline__ double gen_val(const GenObj& o, const GenRow& r, int 
 }
 
 // ------------------------------------------------------------------------------------
+// XCD-affine object mapping of the batched launches of small objects (round 4).  Workgroups are dealt round robin over
+// the 8 XCDs by their linear id (MI355X_MICROARCH.md, workgroup dispatch; cdna_hip_programming.md T1), and every XCD has
+// its own L2: with the plain grid (tiles, 1, objects) the 5-14 tiles of one object's update land on 8 different L2s and
+// each fetches the object's panels from HBM for itself (config 4: 213 MB per launch for 59 MB of distinct panels).  The
+// launch is therefore made with the object count padded to a multiple of 8 and the linear id re-read as
+//   group c = id % 8 (the blocks that share an XCD), slot p = id / 8  ->  object c + 8 (p / gx), tile p % gx:
+// all tiles of an object run on ONE XCD, back to back, and the panels are fetched once.  A pure speed choice: the
+// arithmetic of a tile does not depend on where it runs (same bits, tests/test_gpu_parity.py).
+// Returns false for the padding workgroups (object >= B).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool xcd_affine(int& obj, int& bx, int B) {
+    const int gx = gridDim.x;
+    const int id = blockIdx.x + gx * blockIdx.z;
+    const int c = id & 7, p = id >> 3;
+    obj = c + 8 * (p / gx);
+    bx = p % gx;
+    return obj < B;
+}
+
+// ------------------------------------------------------------------------------------
 // K3: Cholesky of one NB x NB diagonal block, entirely in LDS, one workgroup (4 waves).
 //   8 sub-steps of 16 columns:
 //   (a) wave 0 factors the 16 x 16 diagonal sub-block T in registers: lane r < 16 owns row r;
@@ -636,11 +656,12 @@ __global__ __launch_bounds__(CGP_K3_THREADS) void k_potrf_diag_gen(
 template <int K4W, int GEN = 0>
 __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW,
-    long sW, int blk, int nrows, GenSrc g = GenSrc()) {
+    long sW, int blk, int nrows, GenSrc g = GenSrc(), int xcdB = 0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ls = smem;                               // [128][CGP_LDA] strictly-lower tiles used
     double* Ws = smem + CGP_NB * CGP_LDA;            // [8][16][16]
-    const int b = blockIdx.z;
+    int b = blockIdx.z, bx = blockIdx.x;
+    if (xcdB > 0 && !xcd_affine(b, bx, xcdB)) return;
     M += (long)b * sM;
     wsW += (long)b * sW + (long)blk * (8 * 256);
     const double* Lg = M + (long)c0 * ld + c0;
@@ -650,10 +671,10 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
     // tile rows g = 0, 1 offer columns 16..127 (6 slots of 18), g = 2 columns 32..127 (5 slots); row stride CGP_LDA
     const int xg = wave < 6 ? 0 : (wave < 12 ? 1 : 2), xt = wave - 6 * xg;
     double* Xs = Ls + xg * 16 * CGP_LDA + (xg == 2 ? 32 : 16) + 18 * xt;
-    double* Ap = M + (long)(r0 + blockIdx.x * (16 * K4W) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
+    double* Ap = M + (long)(r0 + bx * (16 * K4W) + wave * 16 + 4 * lb + lq) * ld + c0 + 4 * lu;
     // nrows need not fill the last workgroup (the tall rows of small objects come in units of 64): its surplus waves help
     // to stage L_kk and then have no rows of their own
-    const bool has_rows = (int)(blockIdx.x * (16 * K4W) + wave * 16) < nrows;
+    const bool has_rows = (int)(bx * (16 * K4W) + wave * 16) < nrows;
 
     CGP_STAMP(50);
     // This wave's 16 x 128 panel rows in MFMA result layout.  The column slot (J, u) of a 16-wide
@@ -689,7 +710,7 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
         __syncthreads();
         if (has_rows) {
             const GenObj o = gen_obj<GD>(g, b);
-            const int i = r0 + blockIdx.x * (16 * K4W) + wave * 16 + 4 * lb + lq;
+            const int i = r0 + bx * (16 * K4W) + wave * 16 + 4 * lb + lq;
             const GenRow rw = gen_row<GD>(g, o, i);
 #pragma unroll
             for (int jb = 0; jb < 8; ++jb) {
@@ -783,7 +804,7 @@ template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0, int GEN = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
-    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc()) {
+    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc(), int xcdB = 0) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -794,7 +815,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     static_assert(PA >= 1 && PB >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) double As[2][TM * KS];
     __shared__ __attribute__((aligned(16))) double Bs[2][TN * KS];
-    const int bz = blockIdx.z;
+    int bz = blockIdx.z, bx0 = blockIdx.x;
+    if (xcdB > 0 && !xcd_affine(bz, bx0, xcdB)) return;        // (see xcd_affine: all tiles of an object on one XCD)
     C += (long)bz * sC;
     A += (long)bz * sAB;
     B += (long)bz * sAB;
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     // CUs stay free for the latency-critical leaf kernels of the other stream).
     // tab != nullptr: the launch grid walks a host-built tile list instead (XCD-aligned order, see launch_gemm);
     // entries with x < 0 are padding
-    for (int bid = blockIdx.x + tile_skip; bid < (tab ? ntab : ntot); bid += gridDim.x) {
+    for (int bid = bx0 + tile_skip; bid < (tab ? ntab : ntot); bid += gridDim.x) {
     int ti, tj;
     if (tab) {
         const int2 t = tab[bid];

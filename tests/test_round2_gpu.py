@@ -29,6 +29,7 @@ def _c5_field(n):
     return X[:n], y[:n]
 
 
+@pytest.mark.timeout(900)
 def test_c5_full_size_sweep(cg, monkeypatch):
     """BASELINE config[4]: 2D RBF GP, N = 16384, 32 (sigma, l) pairs, all on one GPU through
     multigpu.sweep_log_likelihood, 4 candidates per lock-step launch sequence.
@@ -89,6 +90,18 @@ def test_c5_full_size_sweep(cg, monkeypatch):
             ref = (-0.5 * ys @ la.cho_solve(cf, ys) - 0.5 * ns * np.log(2 * np.pi)
                    - np.sum(np.log(np.diag(cf[0]))))
         assert abs(v - ref) <= 1e-10 * abs(ref)
+    # Round 4: ONE candidate at the FULL size N = 16384 against the oracle directly -- oracle.rbf_kernel_2d (kernel.py:80-155)
+    # + scipy.linalg.cho_factor on the box's host cores (inv_matrix.py:23, Gaussian_process.py:68-73; ~30 s, 2 GiB matrix) --
+    # with the bound computed from cond_1(K) of that matrix (conftest.oracle_fit_with_bounds)
+    from conftest import oracle_fit_with_bounds
+    row = table[13]
+    Kc = orc.rbf_kernel_2d(X, row, y_err=e, sigma2_in_train=True)
+    o = oracle_fit_with_bounds(Kc, y, np.zeros((0, n)), np.zeros(0))
+    del Kc
+    rl = abs(got[13] - o['ll']) / o['bll']
+    print('C5 candidate 13 at N = 16384: cond_1(K) = %.3g, loglik %.10g against %.10g, |d| / bound = %.3g' % (o['cond'], got[13], o['ll'], rl))
+    assert rl <= 1.
+    assert abs(got[13] - o['ll']) <= 1e-10 * abs(o['ll'])        # (and the flat tolerance SURVEY.md 8(c) proposes)
 
 
 def test_covariance_after_interleaved_calls(cg):
@@ -452,6 +465,53 @@ def test_first_touch_generation_bit_identical_to_assembled(dim, monkeypatch):
     assert not outs[0][1].any()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim,nobj', [(1, 37), (2, 24), (1, 16)])
+def test_xcd_affine_launches_bit_identical_to_plain_grid(dim, nobj, monkeypatch):
+    """Round 4: the batched launches of >= 16 small objects deal their workgroups so that all tiles of an object run on ONE
+    XCD (csrc/kernels.hpp, xcd_affine; object count padded to a multiple of 8, the padding workgroups leave at once).  Where a
+    tile runs does not enter its arithmetic: every output -- ragged lengths, object counts that are not multiples of 8, with and
+    without first-touch generation, prediction rows, log-likelihood only, a sweep -- equals the plain grid (CGP_NO_XCD=1) bit for bit."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(400 + dim + nobj)
+    ns = [int(v) for v in rng.integers(100, 900, nobj)]
+    ns[0], ns[1] = 512, 896
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 19)
+        kp = K.kernel_params_1d([0.9, 2.5], 0.03)
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (19, 2))
+        kp = K.kernel_params_2d([0.9, 4.0, 5.0, 3.0], nugget=0.03)
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    outs = []
+    for xcd, fused in ((True, True), (False, True), (True, False)):
+        monkeypatch.delenv('CGP_NO_XCD', raising=False)
+        monkeypatch.delenv('CGP_NO_FUSED_ASM', raising=False)
+        if not xcd:
+            monkeypatch.setenv('CGP_NO_XCD', '1')
+        if not fused:
+            monkeypatch.setenv('CGP_NO_FUSED_ASM', '1')
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, None, 0.01)
+        r2 = dev.batch_fit(dim, xs, ys, diags, kp, None, None, 0.)          # log-likelihood only
+        dev.set_data(dim, xs[0], ys[0])
+        kps = np.array([K.kernel_params_1d([0.5 + 0.03 * i, 2.0], 0.03) if dim == 1 else
+                        K.kernel_params_2d([0.5 + 0.03 * i, 4., 4., 0.], sigma2_in_train=True, nugget=0.03) for i in range(20)])
+        sweep = dev.sweep_loglik(kps, diags[0])
+        outs.append([r[0], r[1], r[2], r[3], r2[0], np.asarray(sweep[0])])
+        dev.close()
+    assert not outs[0][1].any()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
 
 
 def test_first_touch_generation_randomised_subset(monkeypatch):

@@ -6,7 +6,9 @@ Every update launch of the run is counted (setup, warm-up, timed steps, stage pa
 same shapes), traffic is reported PER LAUNCH like the roofline's flops.
 usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv objects_per_launch out.json [kernel substring]
 (kernel substring: default k_gemm_nt; k_chol_dag for the single-launch factorisation of `bench.py --batch 1 --streams 1`)"""
-import csv, json, sys, collections
+import csv, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 fetch_csv, write_csv, objs, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
 KSUB = sys.argv[5] if len(sys.argv) > 5 else 'k_gemm_nt'
 
@@ -39,6 +41,7 @@ na = max(1, sum(fc[k] for k in asm))
 res = dict(source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`; all update '
                   'launches of the run averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (16-B-per-lane '
                   'loads on gfx950)',
+           kernel_sources_sha256=bench.kernel_source_hash(),
            kernel=KSUB + ' (every launch of the run)', objects_per_launch=objs,
            launches_in_run=launches, fetch_bytes_per_launch=fetch_b, write_bytes_per_launch=write_b,
            traffic_bytes_per_launch=fetch_b + write_b,
