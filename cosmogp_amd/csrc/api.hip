@@ -50,7 +50,12 @@ inline long round_up(long v, long q) { return (v + q - 1) / q * q; }
 // objects large enough for the single-launch factorisation (its tiles are 128 x 128), to 64 rows for the small ones, whose
 // launch-per-step kernels work in units of 64 rows: a light curve of N = 512 predicted at M = 19 points then carries 64
 // tall rows instead of 128 through every solve and update (21 % of the flops of its sweep, 10 % of its time).
-inline long tall_rows(long m, long Np) { return round_up(m + 1, Np >= 2048 ? 128 : 64); }
+inline long tall_rows(long m, long Np, long dag_min_nb = 26) {
+    // (a small object with many prediction points -- N = 1024, M = 2450 -- is single-launch eligible by its tile-row count:
+    // its tall rows are whole tiles too, or the route would depend on m mod 128)
+    const bool whole_tiles = Np >= 2048 || Np / CGP_NB + round_up(m + 1, 128) / CGP_NB > dag_min_nb;
+    return round_up(m + 1, whole_tiles ? 128 : 64);
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -347,6 +352,9 @@ int fail(cgp_handle* h, int code, const char* msg) {
 // Staged device -> host results that were never delivered belong to a call that failed between queueing them and its
 // synchronisation: their destinations (that call's stack, its caller's arrays) may be gone.  Every entry point starts here.
 void drop_stale_staging(cgp_handle* h) {
+    // (their asynchronous copies may still be in flight into / out of the pinned chunk this call is about to reuse: wait for
+    // the stream first, then discard)
+    if (!h->pin_out.empty() || (!h->pin.empty() && h->pin.back().used != 0)) (void)stream_wait(h->stream);
     h->pin_out.clear();
     if (!h->pin.empty()) h->pin.back().used = 0;
 }
@@ -1306,7 +1314,7 @@ int cgp_fit(cgp_handle* h, const double* kp, const double* diag, const double* x
     if (!h->have_data) return fail(h, CGP_E_STATE, "cgp_fit: no data (call cgp_fit_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu))) return fail(h, CGP_E_ARG, "cgp_fit: bad argument");
     Prob& P = h->P;
-    const long Mp = tall_rows(m, P.Np);
+    const long Mp = tall_rows(m, P.Np, h->env.no_dag ? (1l << 30) : h->env.dag_min_nb);
     CHK(bind_single(h, Mp, false));
     CHK(upload_kp(h, kp, kss_noise));
     remember_fit_kp(h, kp, kss_noise);
@@ -1345,7 +1353,7 @@ int cgp_fit_predict(cgp_handle* h, const double* xnew, int64_t m, const double* 
     if (!h->factored) return fail(h, CGP_E_STATE, "cgp_fit_predict: no factor (call cgp_fit first)");
     if (!xnew || m <= 0 || !mu) return fail(h, CGP_E_ARG, "cgp_fit_predict: bad argument");
     Prob& P = h->P;
-    const long Mp = tall_rows(m, P.Np);
+    const long Mp = tall_rows(m, P.Np, h->env.no_dag ? (1l << 30) : h->env.dag_min_nb);
     CHK(bind_single(h, Mp, true));
     const long ld = P.Np;
     CHK(upload_padded(h, h->bxnew, xnew, (size_t)m * P.dim, (size_t)Mp * P.dim));
@@ -2118,7 +2126,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit: no resident batch (call cgp_batch_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
         return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
-    const long Mp = tall_rows(m, Q.Np);
+    const long Mp = tall_rows(m, Q.Np, 1l << 30);        // (batches take the single launch from 16 tile columns on: Np >= 2048)
     Q.R = Q.Np + Mp;
     Q.sM = Q.R * Q.Np;
     Q.kps = 0;                                  // one shared parameter set (a sweep may have left 1)

@@ -488,8 +488,13 @@ __global__ __launch_bounds__(256) void k_pchol_step(const double* __restrict__ K
     __shared__ double sv[PCHOL_ROWS];
     __shared__ int si[PCHOL_ROWS];
     __shared__ double s_p[2];
-    if (ctl->done) return;
+    __shared__ int s_done;
     const int tid = threadIdx.x, rr = tid & 63, q = tid >> 6;
+    // `done` may be set by workgroup 0 of THIS launch while later workgroups start: ONE thread reads it and the whole
+    // workgroup follows that value (every thread reading for itself could split a workgroup around the barrier below)
+    if (tid == 0) { s_done = ctl->done; s_p[0] = -1.; s_p[1] = 0.; }
+    __syncthreads();
+    if (s_done) return;
     // pivot: the largest residual diagonal entry (lowest index on ties), the same in every workgroup
     if (tid < 64) {
         double m = -1.;

@@ -196,7 +196,8 @@ class Gaussian_process(object):
 
     def _res_token(self, sn):
         """Identity of object sn's data in HBM: the handle's data generation, the index, the ids of the arrays it was uploaded
-        from AND a fingerprint of their contents (length, sum, first / middle / last element of y, Time, y_err; y0 and diff):
+        from AND a fingerprint of their contents (length, sum, first / middle / last element of y, Time, y_err and y0 -- `diff` enters
+        through y0 = mean + diff, it is not fingerprinted by itself):
         replacing gp.y[sn] / gp.Time[sn] / gp.y_err[sn] by new arrays is noticed, and so is the usual in-place edit
         (`gp.y_err[0] *= 2`, `gp.y[0][:] = ...`) -- the reference re-reads the arrays on every call
         (Gaussian_process.py:207-211).  An edit that leaves all of these unchanged needs invalidate().  (One O(n) sum per array

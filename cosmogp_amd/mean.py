@@ -21,9 +21,10 @@ def fit_mean_2d(old_binning, mean_function):
     is fitted from scratch (task=0, same defaults); LAST_BISPLREP_TASK says which one ran."""
     global LAST_BISPLREP_TASK
     old_binning = np.asarray(old_binning, dtype=np.float64)
-    mean_function = np.asarray(mean_function, dtype=np.float64)
+    # (bisplrep ravels z: an (n, 1) column or any other layout of the n values works upstream, cosmogp/mean.py:58)
+    mean_function = np.asarray(mean_function, dtype=np.float64).ravel()
     # genuine argument errors are reported as such, never papered over by the second attempt
-    if old_binning.ndim != 2 or old_binning.shape[1] != 2 or mean_function.shape != (old_binning.shape[0],):
+    if old_binning.ndim != 2 or old_binning.shape[1] != 2 or mean_function.size != old_binning.shape[0]:
         raise ValueError('the 2D mean needs coordinates of shape (n, 2) and n mean values, got %r and %r'
                          % (old_binning.shape, mean_function.shape))
     if not (np.all(np.isfinite(old_binning)) and np.all(np.isfinite(mean_function))):

@@ -92,7 +92,15 @@ int cgp_cholesky_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk,
  * with the modes whose singular value is <= thresh (reference: 1e-15) dropped; logdet = sum of the logs
  * of the kept singular values; never fails on singular input.  On the device the SVD of the symmetric K
  * is its eigen-decomposition (two-sided block Jacobi, csrc/jacobi.hpp): s = |lambda|.
- * K: (n, n) row stride ldk, both triangles read.  inv_out: (n, n) dense.  n_dropped may be NULL. */
+ * K: (n, n) row stride ldk, both triangles read.  inv_out: (n, n) dense.  n_dropped may be NULL.
+ * EFFECTIVE THRESHOLD of the low-rank pre-stage (route 1 of cgp_eig_info; matrices of n >= 256 that are numerically rank
+ * deficient): the pivoted Cholesky K = G G^T + E stops at a residual diagonal of 4 eps max K_ii and is accepted when
+ * |E|_F <= 8 n eps max K_ii, so modes below that bound are dropped whatever `thresh` says: the route behaves like
+ * thresh_eff = max(thresh, 8 n eps max K_ii).  For a threshold above that bound the routes agree (tests/test_eigen.py);
+ * at the reference's absolute 1e-15 on a matrix of scale ~1 the full sweeps (route 0) keep the rounding-noise modes between
+ * 1e-15 and the bound (each contributes ~ -30 to logdet and 1 / lambda ~ 1e13..1e15 to the pseudo-inverse), route 1 drops
+ * them: n_dropped and logdet differ between the routes there (no decomposition reproduces those modes: DESIGN.md 4.5);
+ * CGP_JAC_NO_LOWRANK=1 forces route 0. */
 int cgp_svd_inverse(cgp_handle* h, const double* K, int64_t n, int64_t ldk, double thresh,
                     double* inv_out, double* logdet_out, int64_t* n_dropped);
 

@@ -209,6 +209,42 @@ def test_low_rank_pre_stage_equals_full_sweeps(cg, monkeypatch):
     assert nd == 0 and np.abs(Kn @ inv - np.eye(300)).max() < 1e-9
 
 
+def test_low_rank_pre_stage_effective_threshold_is_the_documented_one(cg, monkeypatch):
+    """Round-3 advisor finding, answered by a stated contract (include/cosmogp_hip.h, cgp_svd_inverse): at the reference's
+    ABSOLUTE 1e-15 on a noise-free matrix of scale ~1 the two routes do NOT agree -- the sweeps keep the rounding-noise modes
+    between 1e-15 and 8 n eps max K_ii, the pre-stage drops them -- and that is all they differ by: the pre-stage never drops a
+    mode above its documented effective threshold, it never keeps one the sweeps drop, and the surplus of the sweeps lies
+    entirely below the bound (checked against numpy's eigenvalues of the same matrix)."""
+    from cosmogp_amd import _lib
+    rng = np.random.default_rng(21)
+    n = 400
+    x = np.sort(rng.uniform(0., 40., n))
+    K = orc.rbf_kernel_1d(x, [1.0, 2.0])                         # scale 1, numerically of rank ~60
+    bound = 8. * n * np.finfo(float).eps * K.diagonal().max()
+    w = np.abs(np.linalg.eigvalsh(K))
+    out = {}
+    for mode in ('lowrank', 'full'):
+        if mode == 'full':
+            monkeypatch.setenv('CGP_JAC_NO_LOWRANK', '1')
+        else:
+            monkeypatch.delenv('CGP_JAC_NO_LOWRANK', raising=False)
+        d = _lib.Device(0)
+        inv, ld, nd = d.svd_inverse(K, thresh=1e-15)
+        out[mode] = (ld, nd, d.eig_info()[0])
+        d.close()
+    (ll, dl, rl), (lf, df, rf) = out['lowrank'], out['full']
+    assert rl == 1 and rf == 0
+    assert dl >= df                                              # the pre-stage drops at least what the sweeps drop ...
+    assert n - dl >= np.sum(w > 16. * bound)                     # ... but nothing clearly above its effective threshold,
+    assert n - df >= np.sum(w > 16. * bound)
+    assert n - dl <= np.sum(w > bound / 64.)                     # and keeps nothing the bound says is noise
+    # every extra mode of the sweeps is noise below the bound: it pulls their log-determinant DOWN by at least |log bound| each
+    # (up to the O(bound) errors both routes carry on the smallest shared modes: one unit of slack per kept mode near the bound)
+    if dl > df:
+        near = int(np.sum((w > bound / 64.) & (w < 64. * bound)))
+        assert lf - ll <= (dl - df) * np.log(16. * bound) + 5. * (near + 1)
+
+
 def test_noise_free_prediction_through_the_classes(cg):
     """The reference's default call (svd_method=True) on noise-free data of 400 points, small amplitude (so that the absolute
     1e-15 threshold lies above the rounding noise and the kept / dropped split is a property of the matrix): prediction and
