@@ -47,10 +47,22 @@ def kernel_source_hash():
     the code that ran (`roofline.traffic_source_current`; tests/test_host_logic.py checks the default workload's file)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp', 'api.hip'):
+    # (the device code of every kernel a fit launches; api.hip -- host orchestration -- is left out: it changes with every
+    # entry point added, its schedule constants are recorded in the bench line itself)
+    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp'):
         with open(os.path.join(ROOT, 'cosmogp_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def traffic_file(workload, dag, nobj_pass):
+    """(path, record) of the newest committed PMC traffic file of this workload, or (None, None)"""
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
+        tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json'
+                             % (rnd, workload, ('_single' if nobj_pass == 1 else '_dagbatch') if dag else ''))
+        if os.path.exists(tpath):
+            return tpath, json.load(open(tpath))
+    return None, None
 
 
 def make_workload(name, rank=0, obj=0, nobj=128):
@@ -341,6 +353,43 @@ def multi_gpu_extras(dev, comm, rank, world, local_rank, args):
     except Exception as exc:
         out['c5'] = dict(error=repr(exc)[:300])
     return {'multi_gpu': out}
+
+
+def other_configs(local_rank):
+    """The default line is BASELINE config[2]; the other configurations that fit one GPU -- config[1] (c2), config[3] (c4),
+    config[4] (c5) -- are timed by child processes of THIS run (each its own `bench.py --workload cX`, a timed region of <= 2 s
+    after its warm-up), so that the driver's one command covers every BASELINE configuration: device-resident rate, API rate
+    (host arrays in, results out), the dominant kernel's roofline fraction, the end-to-end fraction and the PMC traffic
+    constant with its currency flag.  A child that fails is reported, never fatal."""
+    import subprocess
+    out = {}
+    for name, steps, warm in (('c2', 10, 2), ('c4', 400, 40), ('c5', 6, 1)):
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--gpus', '1', '--no-cpu-baseline',
+               '--steps', str(steps), '--warmup', str(warm)]
+        env = dict(os.environ, COSMOGP_DEVICE=str(local_rank), CGP_BENCH_NO_CONFIGS='1')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+            env.pop(k, None)
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
+            rf = d.get('roofline') or {}
+            ex = d.get('extra') or {}
+            o = dict(workload=d['config']['workload'], fits_per_sec=d['value'], ms_per_step=d['ms_per_step'], steps=d['steps'],
+                     fits_per_step=d['config']['fits_per_step_per_gpu'], handles=d['config']['handles_per_gpu'],
+                     api_fits_per_sec=rf.get('api_fits_per_sec'),
+                     dominant_kernel=(rf.get('kernel') or '').split(' ')[0], dominant_kernel_frac=rf.get('frac'),
+                     frac_end_to_end=rf.get('frac_end_to_end'), traffic=rf.get('traffic'),
+                     traffic_unit=rf.get('traffic_unit', 'bytes per launch'),
+                     traffic_source_current=rf.get('traffic_source_current'),
+                     single_fit=rf.get('single_fit'), seconds=round(time.perf_counter() - t0, 1))
+            for k in ('api_fits_per_sec_1024_per_call', 'api_fits_per_sec_2callers', 'small_objects'):
+                if k in ex:
+                    o[k] = ex[k]
+            out[name] = o
+        except Exception as exc:
+            out[name] = dict(error=repr(exc)[:300], seconds=round(time.perf_counter() - t0, 1))
+    return out
 
 
 def launch_ranks(n_gpus, script=None, argv=None):
@@ -654,14 +703,14 @@ def main():
             gemm_ms, launches = st[11], max(1., launches)
             flops = nobj_pass * (float(n) ** 3 / 3.0 + float(n) ** 2 * (wl.get('m', 0) + 1))
         ach = flops / (gemm_ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
-        for rnd in ('r03', 'r02', 'r01'):          # HBM bytes per launch from the separate rocprofv3 --pmc passes (NOT this run)
-            tpath = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s%s.json'
-                                 % (rnd, args.workload, ('_single' if nobj_pass == 1 else '_dagbatch') if dag else ''))
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath))['traffic_bytes_per_launch']
-                tsrc = os.path.relpath(tpath, ROOT)
-                break
+        # HBM bytes per launch (per PASS for the launch-per-step route of small objects) from the separate rocprofv3 --pmc
+        # passes (NOT this run); the file records the hash of the device sources it was collected on
+        traffic, tsrc, tcur = None, None, None
+        tpath, trec = traffic_file(args.workload, dag, nobj_pass)
+        if tpath:
+            traffic = trec['traffic_bytes_per_launch']
+            tsrc = os.path.relpath(tpath, ROOT)
+            tcur = trec.get('kernel_sources_sha256') == kernel_source_hash()
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel=('k_chol_dag (persistent launch: one leaf lane per object + ticketed TRSM / update tasks, '
@@ -686,6 +735,12 @@ def main():
             roof['traffic_source'] = ('replayed constant, not measured by this run: %s (PMC FETCH_SIZE x2, gfx950 '
                                       'wide-load correction, + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of '
                                       '`bench.py --no-extras`)' % tsrc)
+            # does the constant belong to the device code that just ran?  (sha256 of csrc/kernels.hpp, rbfmath.hpp, dag.hpp,
+            # dag_tasks.hpp recorded by tools/pmc_traffic.py at collection time; tests/test_host_logic.py checks the default's)
+            roof['traffic_source_current'] = bool(tcur)
+            if batched:
+                roof['traffic_unit'] = 'bytes per pass: every launch of the %d objects (tools/pmc_pass_traffic.py)' % wl['B']
+                roof['traffic_bytes_per_fit'] = round(traffic / wl['B'], 1)
     if not batched and not args.no_extras:
         if 'sweep' in wl:
             dev.fit(kps[0], None)                    # back to one candidate at a time on this handle
@@ -797,6 +852,46 @@ def main():
             extra['api_note'] = ('cgp_batch_fit with host arrays in (upload of all %d objects: coordinates, residuals, diagonals as '
                                  'one (B, n) array each) and loglik / mu / var back on the host, ONE handle, one call after the '
                                  'other; _lists: the same from lists of per-object arrays; _<k>callers: k host threads with a handle each' % wl['B'])
+            # BASELINE config[3] as ONE call on one GPU: all 1024 light curves in one cgp_batch_fit, ONE handle, one caller; the
+            # library deals them into chunks of 256 and uploads chunk k + 1 under the device pass of chunk k (round 4)
+            try:
+                w1k = make_workload('c4', rank, nobj=1024)
+                d1k = [K.diag_term(w1k['n'], e, 0., 0.) for e in w1k['es']]
+                PX, PY, PD = np.stack(w1k['xs']), np.stack(w1k['ys']), np.stack(d1k)
+                o1 = adev.batch_fit(1, PX, PY, PD, wl['kp'], wl['xnew'], None, 0.)
+                assert not o1[1].any() and np.array_equal(o1[2][:wl['B']], out_p[2])       # the same objects, the same bits
+                reps_k = 4
+                t_a = time.perf_counter()
+                for _ in range(reps_k):
+                    adev.batch_fit(1, PX, PY, PD, wl['kp'], wl['xnew'], None, 0.)
+                extra['api_fits_per_sec_1024_per_call'] = round(reps_k * 1024 / (time.perf_counter() - t_a), 2)
+                tb = min(adev.bench_fit(20, stages=False)[0] for _ in range(2))
+                extra['resident_fits_per_sec_1024_one_handle'] = round(1024 / tb * 1e3, 1)
+                del PX, PY, PD, w1k, d1k
+            except Exception as exc:
+                extra['api_fits_per_sec_1024_per_call'] = dict(error=repr(exc)[:200])
+            # the reference's actual use (docs/notebook/1D_kernel_example_with_noise.ipynb, pull.py:51-66): many objects of tens
+            # of points -- 1000 light curves of 40 points, 19 prediction points, one handle
+            try:
+                rs = np.random.default_rng(40)
+                sx = np.sort(rs.uniform(-12., 42., (1000, 40)), axis=1)
+                se = rs.uniform(0.02, 0.1, (1000, 40))
+                sy = 0.5 * np.sin(sx / 8.) + se * rs.standard_normal((1000, 40))
+                sd = se ** 2
+                adev.batch_fit(1, sx, sy, sd, wl['kp'], wl['xnew'], None, 0.)
+                t_a = time.perf_counter()
+                for _ in range(8):
+                    so = adev.batch_fit(1, sx, sy, sd, wl['kp'], wl['xnew'], None, 0.)
+                api_s = 8 * 1000 / (time.perf_counter() - t_a)
+                ts = min(adev.bench_fit(50, stages=False)[0] for _ in range(2))
+                extra['small_objects'] = dict(objects=1000, n=40, m=19, resident_fits_per_sec=round(1000 / ts * 1e3, 1),
+                                              ms_per_pass=round(ts, 4), api_fits_per_sec=round(api_s, 1),
+                                              packed=os.environ.get('CGP_NO_PACK') is None,
+                                              note='1000 x (n = 40, M = 19) per call, one handle; objects of <= 64 points are packed '
+                                                   'two per 128 x 128 tile as a block diagonal (csrc/api.hip, round 4)')
+                assert not so[1].any()
+            except Exception as exc:
+                extra['small_objects'] = dict(error=repr(exc)[:200])
         else:
             def api_one():
                 adev.set_data(wl['dim'], wl['x'], wl['y'])
@@ -844,6 +939,16 @@ def main():
             if roof is not None:
                 roof['frac_of_measured_ceiling'] = round(roof['achieved'] / mfma_tf, 4)
         value = n_gpus * args.steps * units_per_step / elapsed
+        if roof is not None:
+            # end to end: the algorithmic flops of every fit of the timed region, N^3/3 + N^2 (M + 1), over its wall time -- next
+            # to `frac`, which is the dominant kernel alone (for the launch-per-step route of small objects that kernel is 3
+            # of ~20 launches: this is the number to read there)
+            fl_fit = float(wl['n']) ** 3 / 3.0 + float(wl['n']) ** 2 * (wl.get('m', 0) + 1)
+            roof['frac_end_to_end'] = round(value / n_gpus * fl_fit / 1e12 / SPEC_FP64_MFMA_TFLOPS, 4)
+            roof['flops_per_fit'] = fl_fit
+        if (n_gpus == 1 and args.workload == 'c3' and not args.no_extras and 'RANK' not in os.environ
+                and 'CGP_BENCH_NO_CONFIGS' not in os.environ):
+            extra['configs'] = other_configs(local_rank)
         line = dict(metric='gp_fits_per_sec', value=round(value, 4), unit='fits/s', n_gpus=n_gpus,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',

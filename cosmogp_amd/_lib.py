@@ -292,10 +292,9 @@ class Device(object):
         return out
 
     # ---- batched -------------------------------------------------------------------
-    def batch_set_data(self, dim, xs, resids, diags=None):
-        """Upload B objects and keep them resident: lists of per-object arrays (ragged allowed), or -- objects of equal
-        length -- one C-contiguous (B, n[, 2]) / (B, n) / (B, n) array per quantity, which goes down without any per-object
-        work on the host."""
+    @staticmethod
+    def _batch_host_arrays(xs, resids, diags):
+        """(x, resid, diag, ns) as the flat float64 arrays the C ABI takes"""
         B = len(xs)
         packed = (isinstance(xs, np.ndarray) and isinstance(resids, np.ndarray) and resids.ndim == 2 and xs.shape[:2] == resids.shape
                   and (diags is None or (isinstance(diags, np.ndarray) and diags.shape == resids.shape)))
@@ -309,6 +308,14 @@ class Device(object):
             x = _f64(np.concatenate([np.asarray(a, dtype=np.float64).reshape(len(a), -1) for a in xs]).ravel())
             r = _f64(np.concatenate(resids))
             d = None if diags is None else _f64(np.concatenate(diags))
+        return x, r, d, ns
+
+    def batch_set_data(self, dim, xs, resids, diags=None):
+        """Upload B objects and keep them resident: lists of per-object arrays (ragged allowed), or -- objects of equal
+        length -- one C-contiguous (B, n[, 2]) / (B, n) / (B, n) array per quantity, which goes down without any per-object
+        work on the host."""
+        x, r, d, ns = self._batch_host_arrays(xs, resids, diags)
+        B = len(ns)
         self.batch_generation += 1
         st = self._lib.cgp_batch_set_data(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r),
                                           _ptr(d))
@@ -342,8 +349,30 @@ class Device(object):
                   xnew_per_object=False):
         """Upload + fit in one go (see batch_set_data / batch_fit_resident).  xnew: (m,[2]) grid shared by
         all objects, or (B, m,[2]) with xnew_per_object=True."""
-        self.batch_set_data(dim, xs, resids, diags)
-        return self.batch_fit_resident(kp, xnew, mean_new, kss_noise, xnew_per_object)
+        x, r, d, ns = self._batch_host_arrays(xs, resids, diags)
+        B = len(ns)
+        kp = _f64(kp, (7,))
+        ll = np.empty(B)
+        info = np.zeros(B, dtype=np.int32)
+        if xnew is None:
+            m, xn, mu, var, mn = 0, None, None, None, None
+        else:
+            xn = _f64(xnew)
+            m = xn.shape[1] if xnew_per_object else xn.shape[0]
+            if xnew_per_object and xn.shape[0] != B:
+                raise ValueError('per-object grids need shape (B, m[, 2])')
+            mu, var = np.empty((B, m)), np.empty((B, m))
+            mn = None if mean_new is None else _f64(np.broadcast_to(mean_new, (m,)))
+        self.batch_generation += 1
+        # ONE call with the host data: from two chunks of objects on the library runs the upload of chunk k + 1 under the
+        # device pass of chunk k (csrc/api.hip, batch_fit_pipelined)
+        st = self._lib.cgp_batch_fit(self._h, dim, B, ns.ctypes.data_as(ctypes.POINTER(_i64)), _ptr(x), _ptr(r), _ptr(d),
+                                     _ptr(kp), _ptr(xn), m, 1 if xnew_per_object else 0, _ptr(mn), float(kss_noise), _ptr(ll),
+                                     info.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _ptr(mu), _ptr(var))
+        self._check(st, 'cgp_batch_fit')
+        self._batch = (dim, B)
+        self._batch_nmax = int(ns.max()) if B else 0
+        return ll, info, mu, var
 
     def batch_fit_grad_resident(self, kp):
         """Log-likelihood and gradient moment sums of every object of the resident batch, one launch sequence.

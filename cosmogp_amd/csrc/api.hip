@@ -87,6 +87,7 @@ struct Prob {
     long wrow0 = -1, zrow = -1, tri_base = -1;
     int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
     int gen_on = 0;      // 1 / 2: first-touch generation active for this factorisation (kernels.hpp, GenSrc), coordinates of 1 / 2 components
+    int pack = 1, hs = 0, nobj = 0;   // PACKED small objects (kernels.hpp, GenSrc): B tiles of `pack` objects of <= hs points each, nobj objects in all
     GenSrc gen;
     bool batch_api = false;   // bound by a batched entry point: always the launch-per-step route, whatever B, so that an object's
                               // numbers do not depend on how a caller chunks its batches (the single-launch route of cgp_fit
@@ -105,7 +106,7 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0, eig_cond_max = 1e10;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false, no_pack = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -132,6 +133,7 @@ struct CgpEnv {
         eig_no_chol = getenv("CGP_EIG_NO_CHOL") != nullptr;
         no_fused_asm = getenv("CGP_NO_FUSED_ASM") != nullptr;
         no_xcd = getenv("CGP_NO_XCD") != nullptr;
+        no_pack = getenv("CGP_NO_PACK") != nullptr;
         if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
@@ -184,6 +186,8 @@ struct cgp_handle {
     bool dag_maybe_ran = false;          // a single-launch factorisation was issued (eagerly or by a graph replay) since dag_check
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // look-ahead stream (used inside graph capture only)
+    hipStream_t copy_stream = nullptr;  // uploads of the chunks of a pipelined cgp_batch_fit (created on first use)
+    std::vector<hipEvent_t> chunk_events;
     std::vector<hipEvent_t> fork_events;
     size_t fork_used = 0;
     // Look-ahead inside a captured graph (cross-stream hop ~1.5 us there): every launch of the
@@ -217,6 +221,9 @@ struct cgp_handle {
     long jnb = 0;                             // block count the pair table was built for
     int last_sweeps = 0;
     // batched state
+    Prob Qk;                                  // the packed view of the last cgp_batch_fit of small objects (pack > 1), own input buffers
+    DevBuf pkx, pkr, pkd, pkns;
+    bool last_packed = false;
     Prob Q;
     DevBuf qM, qx, qr, qdiag, qxnew, qws, qldp, qinfo, qns, qmean, qmu, qvar, qscal;
     // captured device-side fit (hipGraph), replayed while shapes and buffers stay the same
@@ -289,6 +296,16 @@ void* pin_alloc(cgp_handle* h, size_t bytes) {
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     h->pin.push_back({(char*)p, cap, bytes});
     return p;
+}
+
+// one chunk of at least `bytes` up front (a call that stages many pieces: growing chunk by chunk costs a hipHostMalloc per
+// piece and per call, since stream_sync keeps only the largest chunk)
+void pin_reserve(cgp_handle* h, size_t bytes) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (!h->pin.empty() && h->pin.back().cap - h->pin.back().used >= bytes) return;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return;
+    h->pin.push_back({(char*)p, bytes, 0});
 }
 
 int h2d(cgp_handle* h, void* dst, const void* src, size_t bytes) {
@@ -698,6 +715,13 @@ int launch_assemble_cross(cgp_handle* h, int dim, int B, double* Mrows, long ld,
 // mu / var for the m cross rows [Np, Np+m) against z = last tall row; block m adds the log-likelihood
 int launch_finish(cgp_handle* h, Prob& P, long m, bool with_loglik, bool has_mean) {
     StageScope sc(h, ST_FINISH);
+    if (P.pack > 1) {
+        hipLaunchKernelGGL(k_finish_packed, dim3((unsigned)(P.pack * m + (with_loglik ? P.pack : 0)), 1, P.B), dim3(256), 0, h->stream,
+                           P.M, P.Np, P.sM, (int)P.Np, (int)(P.R - P.pack), (int)m, P.pack, P.hs, P.nobj, has_mean ? P.mean : nullptr,
+                           (const KParams*)h->bkp.p, P.ns, P.mu, P.var, P.sOut, P.scal);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const long blocks = m + (with_loglik ? 1 : 0);
     if (blocks == 0) return 0;
     hipLaunchKernelGGL(k_finish, dim3((unsigned)blocks, 1, P.B), dim3(256), 0, h->stream, P.M, P.Np, P.sM, (int)P.Np,
@@ -808,13 +832,15 @@ int cgp_destroy(cgp_handle* h) {
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
                      &h->box, &h->boxn, &h->bgrad, &h->jK, &h->jV, &h->jVD, &h->jT, &h->jQ, &h->jflags, &h->jpairs,
                      &h->jstat, &h->jlam, &h->jres, &h->lrGt, &h->lrM, &h->lrXt, &h->lrY, &h->lrws, &h->lrldp, &h->lrinfo, &h->lrd, &h->lrpart, &h->lrctl, &h->qM, &h->qx, &h->qr, &h->qdiag, &h->qxnew, &h->qws,
-                     &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal};
+                     &h->qldp, &h->qinfo, &h->qns, &h->qmean, &h->qmu, &h->qvar, &h->qscal, &h->pkx, &h->pkr, &h->pkd, &h->pkns};
     for (DevBuf* b : all) free_buf(*b);
     for (auto& c : h->pin) (void)hipHostFree(c.p);
     for (auto& g : h->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->fork_events) (void)hipEventDestroy(e);
+    for (auto e : h->chunk_events) (void)hipEventDestroy(e);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1146,7 +1172,10 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         g.x = P.x; g.sx = P.sx; g.xnew = P.xnew ? P.xnew : P.x; g.sxn = P.xnew ? P.sxn : 0; g.diag = P.diag; g.sd = P.sd;
         g.resid = P.r; g.sr = P.sr; g.ns = P.ns; g.kpp = (const KParams*)h->bkp.p; g.kps = P.kps;
         g.m = (int)m; g.Np = (int)P.Np; g.zrow = (int)P.zr();
+        g.pack = P.pack; g.hs = P.hs;
+        if (P.pack > 1) g.zrow = (int)(P.R - P.pack);          // one residual row per object of the tile, the last rows
     } else {
+    if (P.pack > 1) return fail(h, CGP_E_STATE, "packed small objects need the first-touch generation");
     {
         StageScope sc(h, ST_ASM_K);
         CHK(launch_assemble_train(h, P.dim, P.B, P.M, ld, P.sM, P.x, P.sx, P.diag, P.sd, P.ns, P.Np, true, true, P.kps));
@@ -1228,7 +1257,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
         h->use_graph = false;
         return device_fit_eager(h, P, m, has_mean);
     }
-    if (h->graphs.size() >= 8) {         // small cache: drop the oldest
+    if (h->graphs.size() >= 16) {        // small cache: drop the oldest (a pipelined batch holds one graph per chunk)
         (void)hipGraphExecDestroy(h->graphs.front().exec);
         (void)hipGraphDestroy(h->graphs.front().graph);
         h->graphs.erase(h->graphs.begin());
@@ -2113,10 +2142,223 @@ int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, con
     return CGP_OK;
 }
 
+// The resident batch of objects of <= 64 points (Q: one 128-point slot per object) fitted with `pack` objects per tile.
+// *done = 1: results delivered; 0: some tile was not positive definite (nothing delivered, the caller runs the unpacked route).
+static int batch_fit_packed(cgp_handle* h, int dim, long B, const double* kp, const double* xnew, long m, const double* mean_new,
+                            double kss_noise, double* loglik, int32_t* info, double* mu, double* var, int* done) {
+    *done = 0;
+    Prob& Q = h->Q;
+    const int hs = Q.n <= 32 ? 32 : 64, pack = NB / hs;
+    const long Bp = round_up(B, pack), tiles = Bp / pack;
+    const long Mp = round_up(pack * (m + 1), 64), sOut = round_up(m + 1, 64);
+    Prob& K = h->Qk;
+    K = Prob();
+    K.B = (int)tiles; K.dim = dim; K.n = Q.n; K.Np = NB; K.R = NB + Mp; K.sM = K.R * NB;
+    K.pack = pack; K.hs = hs; K.nobj = (int)B; K.batch_api = true;
+    CHK(ensure(h, h->pkx, (size_t)Bp * hs * dim * sizeof(double)));
+    CHK(ensure(h, h->pkr, (size_t)Bp * hs * sizeof(double)));
+    CHK(ensure(h, h->pkd, (size_t)Bp * hs * sizeof(double)));
+    CHK(ensure(h, h->pkns, Bp * sizeof(int)));
+    CHK(ensure(h, h->qM, (size_t)tiles * K.sM * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)tiles * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)tiles * sizeof(double)));
+    CHK(ensure(h, h->qinfo, tiles * sizeof(int)));
+    CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
+    CHK(ensure(h, h->qmu, (size_t)B * sOut * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * sOut * sizeof(double)));
+    CHK(upload_kp(h, kp, kss_noise));
+    CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)round_up(std::max(1l, m), 64) * dim));
+    CHK(upload_padded(h, h->qmean, mean_new, mean_new ? (size_t)m : 0, (size_t)sOut));
+    hipLaunchKernelGGL(k_pack_small, dim3((unsigned)Bp), dim3(64), 0, h->stream, (const double*)h->qx.p, (const double*)h->qr.p,
+                       (const double*)h->qdiag.p, (const int*)h->qns.p, (double*)h->pkx.p, (double*)h->pkr.p, (double*)h->pkd.p,
+                       (int*)h->pkns.p, (int)B, (int)Bp, hs, dim);
+    HIPCHK(hipGetLastError());
+    K.M = (double*)h->qM.p;
+    K.x = (double*)h->pkx.p; K.sx = NB * dim;
+    K.r = (double*)h->pkr.p; K.sr = NB;
+    K.diag = (double*)h->pkd.p; K.sd = NB;
+    K.xnew = (double*)h->qxnew.p; K.sxn = 0;
+    K.wsW = (double*)h->qws.p; K.sW = 8 * 256;
+    K.ldp = (double*)h->qldp.p; K.sLd = 1;
+    K.info = (int*)h->qinfo.p;
+    K.ns = (int*)h->pkns.p;
+    K.mean = (double*)h->qmean.p;
+    K.mu = (double*)h->qmu.p; K.var = (double*)h->qvar.p; K.sOut = sOut;
+    K.scal = (double*)h->qscal.p;
+    CHK(device_fit(h, K, m, mean_new != nullptr));
+    std::vector<int> tinfo(tiles);
+    CHK(d2h(h, tinfo.data(), K.info, tiles * sizeof(int)));
+    std::vector<double> sc((size_t)B * 2);
+    CHK(d2h(h, sc.data(), K.scal, sc.size() * sizeof(double)));
+    if (m > 0) {
+        CHK(d2h_2d(h, mu, m * sizeof(double), K.mu, sOut * sizeof(double), m * sizeof(double), B));
+        if (var) CHK(d2h_2d(h, var, m * sizeof(double), K.var, sOut * sizeof(double), m * sizeof(double), B));
+    }
+    CHK(sync_and_check(h));
+    for (long t = 0; t < tiles; ++t) if (tinfo[t] != 0) return 0;
+    for (long b = 0; b < B; ++b) {
+        if (loglik) loglik[b] = sc[2 * b];
+        if (info) info[b] = 0;
+    }
+    h->last_was_batch = true;
+    h->last_packed = true;
+    h->last_m = m;
+    h->last_has_mean = mean_new != nullptr;
+    h->last_kss_noise = kss_noise;
+    *done = 1;
+    return CGP_OK;
+}
+
+// Objects per chunk of a pipelined cgp_batch_fit (below); a call is pipelined from two chunks on.  CGP_PIPE_CHUNK=0: off.
+static long pipe_chunk(long Np) {
+    if (const char* v = getenv("CGP_PIPE_CHUNK")) return atol(v);        // (read per call: a test switches it inside one process)
+    return Np <= 1024 ? 256 : (Np < 2048 ? 64 : 16);
+}
+
+// cgp_batch_fit with host data for MANY objects (round 4): one caller, one handle, and the upload of chunk k + 1 runs under the
+// device pass of chunk k.  The objects are dealt into chunks of pipe_chunk(Np); per chunk the host packs coordinates / residuals /
+// diagonals into pinned staging (that memcpy runs beside the GPU's previous pass too), queues the copies on a COPY stream,
+// records an event, and the compute stream waits for that event before the chunk's launch sequence (its own captured graph:
+// same kernels as the unchunked pass, and an object's numbers do not depend on the chunking: tests).  Results of all chunks
+// come back in one set of copies at the end.  The batch stays resident as ONE batch of B objects.
+static int batch_fit_pipelined(cgp_handle* h, int dim, long B, const int64_t* ns, const double* x, const double* resid,
+                               const double* diag, const double* kp, const double* xnew, long m, int xnew_per_object,
+                               const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu, double* var,
+                               long chunk) {
+    Prob& Q = h->Q;
+    long nmax = 0;
+    std::vector<long> off((size_t)B + 1, 0);
+    for (long b = 0; b < B; ++b) {
+        if (ns[b] <= 0) return fail(h, CGP_E_ARG, "cgp_batch_fit: ns[b] <= 0");
+        nmax = std::max<long>(nmax, ns[b]);
+        off[b + 1] = off[b] + ns[b];
+    }
+    Q = Prob();
+    Q.B = (int)B; Q.dim = dim; Q.n = nmax; Q.Np = round_up(nmax, NB);
+    const long Np = Q.Np, nblk = Np / NB, Mp = tall_rows(m, Np, 1l << 30);
+    Q.R = Np + Mp; Q.sM = Q.R * Np; Q.kps = 0; Q.batch_api = true;
+    CHK(ensure(h, h->qx, (size_t)B * Np * dim * sizeof(double)));
+    CHK(ensure(h, h->qr, (size_t)B * Np * sizeof(double)));
+    CHK(ensure(h, h->qdiag, (size_t)B * Np * sizeof(double)));
+    CHK(ensure(h, h->qns, B * sizeof(int)));
+    CHK(ensure(h, h->qM, (size_t)B * Q.sM * sizeof(double)));
+    CHK(ensure(h, h->qws, (size_t)B * nblk * 8 * 256 * sizeof(double)));
+    CHK(ensure(h, h->qldp, (size_t)B * nblk * sizeof(double)));
+    CHK(ensure(h, h->qinfo, B * sizeof(int)));
+    CHK(ensure(h, h->qscal, (size_t)B * 2 * sizeof(double)));
+    CHK(ensure(h, h->qmu, (size_t)B * Mp * sizeof(double)));
+    CHK(ensure(h, h->qvar, (size_t)B * Mp * sizeof(double)));
+    CHK(upload_kp(h, kp, kss_noise));                   // (synchronises: nothing of this call is in flight yet)
+    if (xnew_per_object && m > 0) {
+        std::vector<double> hxn((size_t)B * Mp * dim, 0.);
+        for (long b = 0; b < B; ++b)
+            std::memcpy(&hxn[(size_t)b * Mp * dim], xnew + (size_t)b * m * dim, m * dim * sizeof(double));
+        CHK(ensure(h, h->qxnew, hxn.size() * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->qxnew.p, hxn.data(), hxn.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(stream_sync(h));
+    } else {
+        CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)Mp * dim));
+    }
+    CHK(upload_padded(h, h->qmean, mean_new, mean_new ? (size_t)m : 0, (size_t)Mp));
+    HIPCHK(stream_sync(h));
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const long nchunks = (B + chunk - 1) / chunk;
+    pin_reserve(h, (size_t)B * Np * (dim + 2) * sizeof(double) + (size_t)B * sizeof(int) + 64 * (4 * nchunks + 4)
+                   + (size_t)B * (2 + 2 * m) * sizeof(double) + 4096);
+    while ((long)h->chunk_events.size() < nchunks) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->chunk_events.push_back(e);
+    }
+    Q.M = (double*)h->qM.p;
+    Q.x = (double*)h->qx.p; Q.sx = Np * dim;
+    Q.r = (double*)h->qr.p; Q.sr = Np;
+    Q.diag = (double*)h->qdiag.p; Q.sd = Np;
+    Q.xnew = (double*)h->qxnew.p; Q.sxn = (xnew_per_object && m > 0) ? Mp * dim : 0;
+    Q.wsW = (double*)h->qws.p; Q.sW = nblk * 8 * 256;
+    Q.ldp = (double*)h->qldp.p; Q.sLd = nblk;
+    Q.info = (int*)h->qinfo.p;
+    Q.ns = (int*)h->qns.p;
+    Q.mean = (double*)h->qmean.p;
+    Q.mu = (double*)h->qmu.p; Q.var = (double*)h->qvar.p; Q.sOut = Mp;
+    Q.scal = (double*)h->qscal.p;
+    for (long c = 0; c < nchunks; ++c) {
+        const long b0 = c * chunk, nb_ = std::min(chunk, B - b0);
+        // ---- pack + queue the uploads of this chunk on the copy stream
+        auto put = [&](double* dst, const double* src, long width) -> int {
+            const size_t bytes = (size_t)nb_ * Np * width * sizeof(double);
+            if (!src) { HIPCHK(hipMemsetAsync(dst, 0, bytes, h->copy_stream)); return 0; }
+            double* st = (double*)pin_alloc(h, bytes);
+            if (!st) return fail(h, CGP_E_HIP, "cgp_batch_fit: no pinned staging");
+            bool full = true;
+            for (long b = 0; b < nb_; ++b) full = full && ns[b0 + b] == Np;
+            if (full) std::memcpy(st, src + off[b0] * width, bytes);
+            else for (long b = 0; b < nb_; ++b) {
+                double* row = st + (size_t)b * Np * width;
+                const long nbb = ns[b0 + b];
+                std::memcpy(row, src + off[b0 + b] * width, (size_t)nbb * width * sizeof(double));
+                std::memset(row + nbb * width, 0, (size_t)(Np - nbb) * width * sizeof(double));
+            }
+            HIPCHK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, h->copy_stream));
+            return 0;
+        };
+        CHK(put(Q.x + b0 * Q.sx, x, dim));
+        CHK(put(Q.r + b0 * Q.sr, resid, 1));
+        CHK(put(Q.diag + b0 * Q.sd, diag, 1));
+        {
+            int* hn = (int*)pin_alloc(h, nb_ * sizeof(int));
+            if (!hn) return fail(h, CGP_E_HIP, "cgp_batch_fit: no pinned staging");
+            for (long b = 0; b < nb_; ++b) hn[b] = (int)ns[b0 + b];
+            HIPCHK(hipMemcpyAsync(Q.ns + b0, hn, nb_ * sizeof(int), hipMemcpyHostToDevice, h->copy_stream));
+        }
+        HIPCHK(hipEventRecord(h->chunk_events[c], h->copy_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->chunk_events[c], 0));
+        // ---- the chunk's launch sequence: the same buffers, viewed from object b0 on
+        Prob Pc = Q;
+        Pc.B = (int)nb_;
+        Pc.M += b0 * Q.sM; Pc.x += b0 * Q.sx; Pc.r += b0 * Q.sr; Pc.diag += b0 * Q.sd; Pc.xnew += b0 * Q.sxn;
+        Pc.wsW += b0 * Q.sW; Pc.ldp += b0 * Q.sLd; Pc.info += b0; Pc.ns += b0;
+        Pc.mu += b0 * Q.sOut; Pc.var += b0 * Q.sOut; Pc.scal += 2 * b0;
+        CHK(device_fit(h, Pc, m, mean_new != nullptr));
+    }
+    std::vector<double> sc((size_t)B * 2);
+    std::vector<int> hinfo(B);
+    // (results larger than one pinned chunk go straight to the caller's arrays: d2h decides)
+    CHK(d2h(h, sc.data(), Q.scal, sc.size() * sizeof(double)));
+    CHK(d2h(h, hinfo.data(), Q.info, B * sizeof(int)));
+    if (m > 0) {
+        CHK(d2h_2d(h, mu, m * sizeof(double), Q.mu, Mp * sizeof(double), m * sizeof(double), B));
+        if (var) CHK(d2h_2d(h, var, m * sizeof(double), Q.var, Mp * sizeof(double), m * sizeof(double), B));
+    }
+    CHK(sync_and_check(h));
+    for (long b = 0; b < B; ++b) {
+        if (loglik) loglik[b] = sc[2 * b];
+        if (info) info[b] = hinfo[b];
+    }
+    h->have_batch = true;
+    h->last_was_batch = true;
+    h->last_m = m;
+    h->last_has_mean = mean_new != nullptr;
+    h->last_kss_noise = kss_noise;
+    return CGP_OK;
+}
+
 int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
                   const double* diag, const double* kp, const double* xnew, int64_t m, int xnew_per_object,
                   const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu,
                   double* var) {
+    if (x && resid && ns && B > 0 && (dim == 1 || dim == 2) && kp && m >= 0 && !(m > 0 && (!xnew || !mu))) {
+        long nmax = 0;
+        for (long b = 0; b < B; ++b) nmax = std::max<long>(nmax, ns[b]);
+        const long chunk = pipe_chunk(round_up(std::max(1l, nmax), NB));
+        // (objects of <= 64 points are packed several per tile instead, below: that halves their work, the pipeline only hides copies)
+        const bool packable = h && nmax <= 64 && !(xnew_per_object && m > 0) && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0;
+        if (chunk > 0 && B >= 2 * chunk && !packable) {
+            CHK(begin_call(h));
+            return batch_fit_pipelined(h, dim, B, ns, x, resid, diag, kp, xnew, m, xnew_per_object, mean_new, kss_noise, loglik,
+                                       info, mu, var, chunk);
+        }
+    }
     if (x || resid) {          // data given: upload it first; x == resid == NULL: use the resident batch
         int st = cgp_batch_set_data(h, dim, B, ns, x, resid, diag);
         if (st != 0) return st;
@@ -2126,6 +2368,14 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit: no resident batch (call cgp_batch_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
         return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
+    h->last_packed = false;
+    if (Q.Np == NB && Q.n <= 64 && B >= 2 && !(xnew_per_object && m > 0) && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0) {
+        // objects of <= 64 (<= 32) points: two (four) per 128 x 128 tile as a block diagonal (kernels.hpp, GenSrc)
+        int done = 0;
+        const int st = batch_fit_packed(h, dim, B, kp, xnew, m, mean_new, kss_noise, loglik, info, mu, var, &done);
+        if (st < 0 || done) return st;
+        // (a tile met a non-positive pivot: its objects share the garbage behind it -- every object is refitted on its own tile)
+    }
     const long Mp = tall_rows(m, Q.Np, 1l << 30);        // (batches take the single launch from 16 tile columns on: Np >= 2048)
     Q.R = Q.Np + Mp;
     Q.sM = Q.R * Q.Np;
@@ -2499,7 +2749,7 @@ int cgp_bench_fit(cgp_handle* h, int iters, double* ms_per_fit, double* stage_ms
     if (iters <= 0 || !ms_per_fit) return fail(h, CGP_E_ARG, "cgp_bench_fit: bad argument");
     if (!h->last_was_batch && (!h->have_data || !h->P.M || !h->P.xnew))
         return fail(h, CGP_E_STATE, "cgp_bench_fit: run cgp_fit or cgp_batch_fit first");
-    Prob& P = h->last_was_batch ? h->Q : h->P;
+    Prob& P = h->last_was_batch ? (h->last_packed ? h->Qk : h->Q) : h->P;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

@@ -292,9 +292,17 @@ struct GenSrc {
     const KParams* kpp = nullptr; int kps = 0;
     int m = 0, Np = 0, zrow = 0;
     int row0 = 0, col0 = 0;          // absolute (row, column) of the origin of the launch's region
+    // PACKED small objects (round 4): pack = 2 / 4 objects of <= hs = 64 / 32 points share one 128 x 128 tile as a block
+    // diagonal (the Cholesky factor of a block-diagonal matrix is the block diagonal of the factors, and the products with
+    // the zero blocks are exact zeros: every object's numbers are those of its own tile, bit for bit).  Matrix row / column i
+    // belongs to local object i / hs; the coordinate / diagonal / residual arrays hold hs entries per object, so a tile's 128
+    // entries are its objects' arrays back to back; ns has `pack` entries per tile; tall rows: pack x m cross rows (object
+    // lo: rows Np + lo m ..., shared grid only), zero rows, then one residual row per object at zrow + lo.  hs = 0: unpacked.
+    int pack = 1, hs = 0;
 };
-struct GenObj { const double* x; const double* xnew; const double* diag; const double* resid; KParams kp; double yinv; int n; bool dvi; };
-struct GenRow { double vx, vy, dg; int kind; };      // kind 0 train row, 1 identity padding, 2 cross row, 3 zero row, 4 residual
+struct GenObj { const double* x; const double* xnew; const double* diag; const double* resid; const int* ns; KParams kp; double yinv; int n; bool dvi; };
+// kind 0 train row, 1 identity padding, 2 cross row, 3 zero row, 4 residual; the row's object owns columns [c0, c0 + n)
+struct GenRow { double vx, vy, dg; int kind, c0, n; };
 
 template <int DIM>
 __device__ __forceinline__ GenObj gen_obj(const GenSrc& g, int b) {
@@ -302,7 +310,8 @@ __device__ __forceinline__ GenObj gen_obj(const GenSrc& g, int b) {
     o.x = g.x + (long)b * g.sx; o.xnew = g.xnew + (long)b * g.sxn; o.diag = g.diag + (long)b * g.sd; o.resid = g.resid + (long)b * g.sr;
     o.kp = g.kpp[(long)b * g.kps];
     o.yinv = rbf_arg_const<DIM>(o.kp);
-    o.n = g.ns[b];
+    o.ns = g.ns + (long)b * g.pack;
+    o.n = o.ns[0];
     o.dvi = DIM == 2 && o.kp.p1 == 0. && o.kp.p2 == 0.;
     return o;
 }
@@ -310,16 +319,24 @@ template <int DIM>
 __device__ __forceinline__ GenRow gen_row(const GenSrc& g, const GenObj& o, int i) {
     GenRow r;
     r.vx = 0.; r.vy = 0.; r.dg = 0.;
+    r.c0 = 0; r.n = o.n;
     if (i < g.Np) {
-        r.kind = i < o.n ? 0 : 1;
+        int il = i;
+        if (g.hs) { const int lo = i / g.hs; r.c0 = lo * g.hs; r.n = o.ns[lo]; il = i - r.c0; }
+        r.kind = il < r.n ? 0 : 1;
         r.vx = o.x[(long)i * DIM];
         if (DIM == 2) r.vy = o.x[(long)i * DIM + 1];
-        if (i < o.n) r.dg = o.kp.amp_train + (o.diag[i] + o.kp.nug2);
-    } else if (i - g.Np < g.m) {
+        if (il < r.n) r.dg = o.kp.amp_train + (o.diag[i] + o.kp.nug2);
+    } else if (i - g.Np < g.pack * g.m) {
+        int t = i - g.Np;
+        if (g.hs) { const int lo = t / g.m; r.c0 = lo * g.hs; r.n = o.ns[lo]; t -= lo * g.m; }
         r.kind = 2;
-        r.vx = o.xnew[(long)(i - g.Np) * DIM];
-        if (DIM == 2) r.vy = o.xnew[(long)(i - g.Np) * DIM + 1];
-    } else r.kind = i == g.zrow ? 4 : 3;
+        r.vx = o.xnew[(long)t * DIM];
+        if (DIM == 2) r.vy = o.xnew[(long)t * DIM + 1];
+    } else if (i >= g.zrow && i < g.zrow + g.pack) {
+        r.kind = 4;
+        if (g.hs) { const int lo = i - g.zrow; r.c0 = lo * g.hs; r.n = o.ns[lo]; }
+    } else r.kind = 3;
     return r;
 }
 // entry (i, c) of the object's assembled matrix; (ux, uy) = the point of column c
@@ -328,10 +345,11 @@ __device__ __forceinline__ double gen_val(const GenObj& o, const GenRow& r, int 
 #pragma clang fp contract(off)
     if (r.kind == 1) return c == i ? 1. : 0.;
     if (r.kind == 3) return 0.;
-    if (r.kind == 4) return c < o.n ? o.resid[c] : 0.;
+    const bool mine = c >= r.c0 && c < r.c0 + r.n;           // (unpacked: c0 = 0, n = the object's length)
+    if (r.kind == 4) return mine ? o.resid[c] : 0.;
     const double a = o.dvi ? rbf_exp_arg<DIM, true>(ux, uy, r.vx, r.vy, o.kp, o.yinv) : rbf_exp_arg<DIM, false>(ux, uy, r.vx, r.vy, o.kp, o.yinv);
     const double e = (r.kind == 0 ? o.kp.amp_train : o.kp.amp_cross) * rbf_exp(a, etab);
-    if (c >= o.n) return 0.;
+    if (!mine) return 0.;
     return (r.kind == 0 && c == i) ? r.dg : e;
 }
 
@@ -1071,6 +1089,77 @@ __global__ __launch_bounds__(256) void k_finish(
             scal[b * 2 + 0] = -0.5 * s1 - 0.5 * n * 1.8378770664093453 - 0.5 * s2;   // log(2 pi)
             scal[b * 2 + 1] = s2;
         }
+    }
+}
+
+// K7p: finish of PACKED small objects (GenSrc: `pack` objects of <= hs points per 128 x 128 tile).  Block t < pack m: local
+// object lo = t / m, its cross row t of the tile's tall rows against ITS solved residual row zrow + lo -- both are zero
+// outside the object's columns, so the 128-column dot products are the object's own, summed in k_finish's order.  Blocks
+// pack m + lo: the object's log-likelihood, its log-determinant from the diagonal of ITS block of L (the 64-lane tree of
+// k_potrf_diag's reduction with zeros beyond the block: the bits of the object factored alone in a tile).
+__global__ __launch_bounds__(256) void k_finish_packed(
+    const double* __restrict__ M, long ld, long sM, int Np, int zrow, int m, int pack, int hs, int nobj,
+    const double* __restrict__ mean_new, const KParams* __restrict__ kpp, const int* __restrict__ ns,
+    double* __restrict__ mu, double* __restrict__ var, long sOut, double* __restrict__ scal) {
+    const int b = blockIdx.z, t = blockIdx.x;
+    const int lo = t < pack * m ? t / m : t - pack * m;
+    const int obj = b * pack + lo;
+    if (obj >= nobj) return;
+    M += (long)b * sM;
+    const double* z = M + (long)(zrow + lo) * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red[2][4];
+    double s1 = 0., s2 = 0.;
+    if (t < pack * m) {
+        const double* w = M + (long)(Np + t) * ld;
+        for (int c = tid * 2; c < Np; c += 512) {
+            d2 wv = *(const d2*)(w + c), zv = *(const d2*)(z + c);
+            s1 += wv.x * zv.x + wv.y * zv.y;
+            s2 += wv.x * wv.x + wv.y * wv.y;
+        }
+    } else {
+        for (int c = tid * 2; c < Np; c += 512) {
+            d2 zv = *(const d2*)(z + c);
+            s1 += zv.x * zv.x + zv.y * zv.y;
+        }
+        // 2 log L_ii of this object's block in lanes 0 .. hs - 1 of wave 0 (k_potrf_diag: one value per thread, zeros = log 1 beyond)
+        if (tid < hs) s2 = 2. * log(M[(long)(lo * hs + tid) * ld + lo * hs + tid]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+    }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        if (t < pack * m) {
+            s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            const int tt = t - lo * m;
+            mu[(long)obj * sOut + tt] = s1 + (mean_new ? mean_new[tt] : 0.);
+            var[(long)obj * sOut + tt] = (kpp->amp_train + kpp->kss_noise) - s2;
+        } else {
+            s2 = red[1][0] + red[1][1];          // (k_potrf_diag adds the sums of its waves 0 and 1)
+            const double n = (double)ns[obj];
+            scal[obj * 2 + 0] = -0.5 * s1 - 0.5 * n * 1.8378770664093453 - 0.5 * s2;   // log(2 pi)
+            scal[obj * 2 + 1] = s2;
+        }
+    }
+}
+
+// resident unpacked batch ([B][128] per quantity) -> packed arrays ([B][hs], i.e. [tiles][128]); objects beyond B: zeros, n = 0
+__global__ void k_pack_small(const double* __restrict__ x, const double* __restrict__ r, const double* __restrict__ d,
+                             const int* __restrict__ ns, double* __restrict__ px, double* __restrict__ pr,
+                             double* __restrict__ pd, int* __restrict__ pns, int B, int Bpad, int hs, int dim) {
+    const int obj = blockIdx.x, tid = threadIdx.x;
+    if (obj >= Bpad) return;
+    const bool real = obj < B;
+    if (tid == 0) pns[obj] = real ? ns[obj] : 0;
+    for (int i = tid; i < hs; i += blockDim.x) {
+        pr[(long)obj * hs + i] = real ? r[(long)obj * 128 + i] : 0.;
+        pd[(long)obj * hs + i] = real ? d[(long)obj * 128 + i] : 0.;
+        for (int k = 0; k < dim; ++k) px[((long)obj * hs + i) * dim + k] = real ? x[((long)obj * 128 + i) * dim + k] : 0.;
     }
 }
 

