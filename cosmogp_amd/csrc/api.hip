@@ -87,6 +87,7 @@ struct Prob {
     long wrow0 = -1, zrow = -1, tri_base = -1;
     int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
     int gen_on = 0;      // 1 / 2: first-touch generation active for this factorisation (kernels.hpp, GenSrc), coordinates of 1 / 2 components
+    long rv = 0;         // > 0: rows [rv, R) carry nothing (compact tall rows of a small object: cross rows, then the residual row(s), padded to 16)
     int pack = 1, hs = 0, nobj = 0;   // PACKED small objects (kernels.hpp, GenSrc): B tiles of `pack` objects of <= hs points each, nobj objects in all
     GenSrc gen;
     bool batch_api = false;   // bound by a batched entry point: always the launch-per-step route, whatever B, so that an object's
@@ -460,7 +461,7 @@ int xcd_objects(cgp_handle* h, long B, long groups_per_object) {
 int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double* A, const double* Bm,
                 long ld, long sAB, long rows, long cols, long K, bool tri, double alpha, double beta,
                 hipStream_t stream = nullptr, int tile_skip = 0, int bulk_cap = 0, bool ktri = false,
-                const GenSrc* gen = nullptr, int gen_dim = 0) {
+                const GenSrc* gen = nullptr, int gen_dim = 0, long rows_valid = 0) {
     if (rows <= 0 || cols <= 0 || K <= 0) return 0;
     if (!stream) stream = h->stream;
     if (bulk_cap == 0 && B == 1 && tile_skip == 0 && !ktri && h->env.bulk_cap > 0 && rows % 128 == 0 && cols % 128 == 0) {
@@ -529,13 +530,13 @@ int launch_gemm(cgp_handle* h, int B, double* C, long ldc, long sC, const double
         const GenSrc g0 = gen ? *gen : GenSrc();
         if (gen && gen_dim == 1)
             hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 1>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb, (int)rows_valid);
         else if (gen)
             hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL, 0, 2>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
+                               (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb, (int)rows_valid);
         else
         hipLaunchKernelGGL((k_gemm_nt<64, 64, GEMM_SMALL_WM, GEMM_SMALL_WN, GEMM_KB_SMALL>), g, dim3(64 * GEMM_SMALL_WM * GEMM_SMALL_WN), 0, stream, C, ldc, sC, A, Bm, ld, sAB,
-                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb);
+                           (int)K, (int)nr, (int)nc, tri ? 1 : 0, alpha, beta, tile_skip, ktri ? 1 : 0, 0, (const int2*)nullptr, 0, g0, xb, (int)rows_valid);
         }
     }
     HIPCHK(hipGetLastError());
@@ -625,7 +626,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             CHK(launch_potrf(h, P, c0, S));
         }
         const long r0 = chol ? c0 + NB : rlo;
-        const long Re = P.rend(R, c0 + NB);
+        const long Re = P.rv > 0 ? std::min(P.rend(R, c0 + NB), P.rv) : P.rend(R, c0 + NB);
         if (Re > r0) {
             StageScope sc(h, ST_TRSM);
             // 16 rows per wave; one workgroup holds L_kk in LDS and is alone on its CU, so use the fewest
@@ -642,7 +643,7 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
             else if ((rows / 64) * P.B > cus) w = ((rows / 128) * P.B > cus && rows % 256 == 0) ? 16 : 8;
             // (rows is a multiple of 64; with 8 waves the last workgroup of an odd number of 64-row groups is half full, which
             // costs less than the twice as many 4-wave workgroups each staging L_kk for itself)
-            if (rows % 64 != 0) w = 4;
+            if (rows % 16 != 0) w = 4;             // (a wave solves 16 rows; the last workgroup may be part empty: nrows)
             const long groups = (rows + 16 * w - 1) / (16 * w);
             const int xb = xcd_objects(h, P.B, groups);               // the workgroups of an object share L_kk: one XCD (xcd_affine)
             const dim3 g((unsigned)groups, 1, (unsigned)(xb ? round_up(P.B, 8) : P.B));
@@ -668,16 +669,17 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
         return factor_range(h, P, mid, c1, rlo, R, chol);
     }
     const long rs = chol ? mid : rlo;
+    const long rvalid = (P.rv > 0 && P.rv < P.rend(R, mid)) ? std::max(1l, P.rv - rs) : 0;      // rows of the update that carry data
     if (chol) CHK(dep_wait(h, S, mid / NB, c1 / NB));
     if (P.gen_on && chol && c0 == 0) {
         // the one update launch that touches block columns [mid, c1) first: its "C" is computed (kernels.hpp, GenSrc)
         GenSrc g = P.gen;
         g.row0 = (int)rs; g.col0 = (int)mid;
         CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
-                        P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S, 0, 0, false, &g, P.gen_on));
+                        P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S, 0, 0, false, &g, P.gen_on, rvalid));
     } else
     CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
-                    P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S));
+                    P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S, 0, 0, false, nullptr, 0, rvalid));
     return factor_range(h, P, mid, c1, rlo, R, chol);
 }
 
@@ -717,7 +719,7 @@ int launch_finish(cgp_handle* h, Prob& P, long m, bool with_loglik, bool has_mea
     StageScope sc(h, ST_FINISH);
     if (P.pack > 1) {
         hipLaunchKernelGGL(k_finish_packed, dim3((unsigned)(P.pack * m + (with_loglik ? P.pack : 0)), 1, P.B), dim3(256), 0, h->stream,
-                           P.M, P.Np, P.sM, (int)P.Np, (int)(P.R - P.pack), (int)m, P.pack, P.hs, P.nobj, has_mean ? P.mean : nullptr,
+                           P.M, P.Np, P.sM, (int)P.Np, (int)P.zr(), (int)m, P.pack, P.hs, P.nobj, has_mean ? P.mean : nullptr,
                            (const KParams*)h->bkp.p, P.ns, P.mu, P.var, P.sOut, P.scal);
         HIPCHK(hipGetLastError());
         return 0;
@@ -1171,9 +1173,15 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         GenSrc& g = P.gen;
         g.x = P.x; g.sx = P.sx; g.xnew = P.xnew ? P.xnew : P.x; g.sxn = P.xnew ? P.sxn : 0; g.diag = P.diag; g.sd = P.sd;
         g.resid = P.r; g.sr = P.sr; g.ns = P.ns; g.kpp = (const KParams*)h->bkp.p; g.kps = P.kps;
-        g.m = (int)m; g.Np = (int)P.Np; g.zrow = (int)P.zr();
+        g.m = (int)m; g.Np = (int)P.Np;
         g.pack = P.pack; g.hs = P.hs;
-        if (P.pack > 1) g.zrow = (int)(P.R - P.pack);          // one residual row per object of the tile, the last rows
+        // compact tall rows (round 4): the residual row(s) sit right behind the cross rows, and everything from the next
+        // multiple of 16 on is skipped by the solves (k_trsm_panel: nrows) and by the updates (k_gemm_nt: rows_valid) -- the
+        // 20 real tall rows of a light curve predicted at 19 points used to ride as 64 through every solve and update
+        P.zrow = P.Np + P.pack * m;
+        g.zrow = (int)P.zrow;
+        P.rv = P.Np + round_up(P.pack * (m + 1), 16);
+        if (P.rv >= P.R) P.rv = 0;
     } else {
     if (P.pack > 1) return fail(h, CGP_E_STATE, "packed small objects need the first-touch generation");
     {
@@ -1200,6 +1208,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
     else {
         const int st = factor_range(h, P, 0, P.Np, 0, P.R, true);
         P.gen_on = 0;
+        if (st < 0 && fuse) { P.zrow = -1; P.rv = 0; }
         CHK(st);
     }
     if (h->trk.active) {
@@ -1209,7 +1218,9 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         HIPCHK(hipEventRecord(e1, h->stream2));
         HIPCHK(hipStreamWaitEvent(h->stream, e1, 0));
     }
-    CHK(launch_finish(h, P, m, true, has_mean));
+    const int stf = launch_finish(h, P, m, true, has_mean);
+    if (fuse) { P.zrow = -1; P.rv = 0; }             // (the compact layout belongs to this pass only: cgp_fit_predict re-solves its own)
+    CHK(stf);
     return 0;
 }
 

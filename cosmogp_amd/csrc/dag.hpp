@@ -42,7 +42,7 @@ struct DagParams {
     const int4* tasks;      // {i | (object << 16), j, k0, (k1 << 1) | type}   type 0 = TRSM (panel j), 1 = UPD
     int ntasks;
     unsigned* state;        // [nmat][nr * nb]
-    unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)  [3] progress of leaf lane 0
+    unsigned* ctrl;         // [0] ticket  [1] abort code  [2] first failing wait (diagnostic)  [3] progress of leaf lane 0  [4] workgroups arrived (roles)
     unsigned* sticky;       // [0] abort code  [1] failing wait  [2] ticket head then: the FIRST give-up of any launch on this handle since
                             // the host last looked (never reset by a launch: graph replays and chunked sequences reuse `ctrl`)
     double* wsW;            // [nb][8][256] T^-T blocks of the diagonal tiles (also read by later solves)
@@ -696,14 +696,30 @@ __device__ __forceinline__ void dag_note_abort(const DagParams& p) {
     }
 }
 
+// this workgroup's arrival number in the launch (ctrl[4]; the launch's control block starts zeroed)
+__device__ __noinline__ int dag_role(unsigned* ctrl) {
+    extern __shared__ __attribute__((aligned(16))) double smem_r[];
+    int* cw = (int*)(smem_r + DAG_LDS_DOUBLES);
+    if (threadIdx.x == 0) cw[6] = (int)__hip_atomic_fetch_add((gu32*)(ctrl + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return cw[6];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(DAG_THREADS) void k_chol_dag(DagParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int* cw = (int*)(smem + DAG_LDS_DOUBLES);       // [0] wait result, [1..5] ticket + descriptor
-    if ((int)blockIdx.x < p.nmat) {
-        if (p.dbg != 9) dag_leaf(p, smem, (int)blockIdx.x);   // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
+    // Roles by ARRIVAL, not by block id (round 4): the first nmat workgroups to become resident are the leaf lanes.  With roles
+    // by block id a launch could end up with workers resident and a leaf lane not -- the dispatcher deals blocks to the XCDs
+    // independently, block 0 can queue for a CU of its XCD while later blocks start elsewhere -- and when several persistent
+    // launches compete for the CUs (four host threads, tests/test_dag.py) two of them could hold each other's CUs with
+    // workers that spin for leaf lanes that never start: the bounded spins then gave up after 4 s.  By arrival, every
+    // resident worker belongs to a launch whose leaf lanes are all resident, so it can always make progress.
+    const int role = __builtin_amdgcn_readfirstlane(dag_role(p.ctrl));
+    if (role < p.nmat) {
+        if (p.dbg != 9) dag_leaf(p, smem, role);   // 9: update-task benchmark of tools/dag_probe.hip, no leaf lane
         dag_note_abort(p);
         return;
     }

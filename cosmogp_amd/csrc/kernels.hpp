@@ -822,7 +822,8 @@ template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0, int GEN = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
-    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc(), int xcdB = 0) {
+    int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc(), int xcdB = 0,
+    int rows_valid = 0) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int MT = TM / WM / 16;          // A fragments (16 rows each) per wave
     constexpr int NJ = TN / WN / 4;           // B column groups (4 cols each) per wave
@@ -904,6 +905,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     const int kstart = ktri ? ti * TM : 0;
     const double* Ag = A + (long)(ti * TM) * ld + kstart;
     const double* Bg = B + (long)(tj * TN) * ld + kstart;
+    // Waves without useful work sit the tile out (round 4; they still stage and keep the barriers): (i) rows_valid > 0: rows of
+    // the C region from rows_valid on carry nothing (the tall rows of a small object are padded to the 64-row tile, 20 of 64
+    // are real: a quarter of the tiles of a 512-point light curve are tall-row tiles) -- a wave whose rows all lie beyond
+    // neither computes nor stores, and its share of the A stage is not even loaded; (ii) a tile on the diagonal of a
+    // triangular region: the wave tiles entirely above the diagonal.  What IS computed is computed as before: same bits.
+    const bool wave_on = !((rows_valid > 0 && ti * TM + wm * (TM / WM) >= rows_valid) ||
+                           (tri && RT == 1 && bid < ntri && ti == tj && wn * (TN / WN) > wm * (TM / WM) + (TM / WM) - 1));
+    const bool arow_on = !(rows_valid > 0 && ti * TM + srow >= rows_valid);        // (PA = 1 for the small form: one row per thread)
 
     double acc[MT][NJ];
 #pragma unroll
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double cv[EARLYC ? MT : 1][EARLYC ? NJ : 1];
     if (GEN != 0) {
         // (computed below, once the first two stage loads are on their way)
-    } else if (EARLYC && beta != 0.) {
+    } else if (EARLYC && beta != 0. && wave_on) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
         constexpr int P = decltype(par)::value;
         const int k1 = kt * KB + sch;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) ra[P][p] = *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + k1);
+        for (int p = 0; p < PA; ++p) ra[P][p] = (PA > 1 || arow_on) ? *(const d2*)(Ag + (long)(srow + RSTEP * p) * ld + k1) : (d2){0., 0.};
 #pragma unroll
         for (int p = 0; p < PB; ++p) rb[P][p] = *(const d2*)(Bg + (long)(srow + RSTEP * p) * ld + k1);
     };
@@ -945,6 +954,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
         for (int p = 0; p < PB; ++p) *(d2*)(&Bs[buf][(srow + RSTEP * p) * KS + sch]) = rb[P][p];
     };
     auto compute = [&](int cur, int kt) {
+        if (!wave_on) return;
         d2 fa[MT], fb[NJ];
         if (ABLATE >= 2) {
 #pragma unroll
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     gload(P0{}, 0);
     gload(P1{}, 1);
     __builtin_amdgcn_sched_barrier(0);      // keep the loads where they are written (see above)
-    if (GEN != 0) {
+    if (GEN != 0 && wave_on) {
         const GenObj o = gen_obj<GD>(g, bz);
         const int rr0 = g.row0 + ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq, cc0 = g.col0 + tj * TN + wn * (TN / WN) + lp;
         double ux[NJ], uy[NJ];
@@ -1016,7 +1026,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
         __syncthreads();
     }
 
-    if (EARLYC && beta != 0.) {
+    if (!wave_on) {
+        // (nothing to store)
+    } else if (EARLYC && beta != 0.) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
