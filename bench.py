@@ -49,7 +49,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     # (the device code of every kernel a fit launches; api.hip -- host orchestration -- is left out: it changes with every
     # entry point added, its schedule constants are recorded in the bench line itself)
-    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp'):
+    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp', 'smallchol.hpp'):
         with open(os.path.join(ROOT, 'cosmogp_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -702,6 +702,12 @@ def main():
             # cross rows and the residual row ride through the same sweep); one launch per group of objects
             gemm_ms, launches = st[11], max(1., launches)
             flops = nobj_pass * (float(n) ** 3 / 3.0 + float(n) ** 2 * (wl.get('m', 0) + 1))
+        ll_route = (not dag) and gemm_ms == 0.
+        if ll_route:
+            # small objects on the left-looking panel route (csrc/smallchol.hpp): no update launches at all -- the dominant kernels
+            # are k_ll_diag + k_ll_slab (+ the diagonal-block / panel-solve kernels of panel 0): the whole factorisation
+            gemm_ms, launches = st[1] + st[2], max(1., 2. + 3. * (-(-n // 128) - 1))
+            flops = nobj_pass * (float(n) ** 3 / 3.0 + float(n) ** 2 * (wl.get('m', 0) + 1))
         ach = flops / (gemm_ms * 1e-3) / 1e12
         # HBM bytes per launch (per PASS for the launch-per-step route of small objects) from the separate rocprofv3 --pmc
         # passes (NOT this run); the file records the hash of the device sources it was collected on
@@ -714,7 +720,10 @@ def main():
         roof = dict(bound='mfma', achieved=round(ach, 3), peak=SPEC_FP64_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / SPEC_FP64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel=('k_chol_dag (persistent launch: one leaf lane per object + ticketed TRSM / update tasks, '
-                            'v_mfma_f64_4x4x4_4b_f64)' if dag else 'k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms'),
+                            'v_mfma_f64_4x4x4_4b_f64)' if dag else
+                            ('k_ll_diag + k_ll_slab (left-looking panels of small objects, csrc/smallchol.hpp) with k_potrf_diag / k_trsm_panel '
+                             'for panel 0: every launch of the factorisation' if ll_route else
+                             'k_gemm_nt (v_mfma_f64_4x4x4_4b_f64), both tile forms')),
                     launches_per_fit=int(launches),
                     flops_per_launch=flops / launches, avg_launch_ms=round(gemm_ms / launches, 5),
                     objects_per_launch=lock,
@@ -966,7 +975,9 @@ def main():
                                                  'the host, PCIe included',
                                 factorisation_route=('single launch: persistent tile-DAG kernel k_chol_dag, one leaf lane per object'
                                                      if (roof is not None and 'k_chol_dag' in roof['kernel'])
-                                                     else 'one launch per step: k_potrf_diag / k_trsm_panel / k_gemm_nt'),
+                                                     else ('left-looking panels: k_potrf_diag / k_trsm_panel (panel 0), k_ll_diag / k_ll_slab'
+                                                           if (roof is not None and 'k_ll_diag' in roof['kernel'])
+                                                           else 'one launch per step: k_potrf_diag / k_trsm_panel / k_gemm_nt')),
                                 parallelism='independent fits, 1 rank per GPU, %d handles (HIP streams) per GPU, '
                                             '%d distinct objects per launch sequence' % (nstreams, wl['B'] if batched else lock)),
                     roofline=roof)

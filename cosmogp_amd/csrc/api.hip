@@ -4,6 +4,7 @@
 #include "jacobi.hpp"
 #include "dag.hpp"
 #include "dag_tasks.hpp"
+#include "smallchol.hpp"
 #include "spline.hpp"
 #include "../../include/cosmogp_hip.h"
 
@@ -107,7 +108,7 @@ struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0, eig_cond_max = 1e10;
     long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false, no_pack = false;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false, no_pack = false, ll = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -135,6 +136,7 @@ struct CgpEnv {
         no_fused_asm = getenv("CGP_NO_FUSED_ASM") != nullptr;
         no_xcd = getenv("CGP_NO_XCD") != nullptr;
         no_pack = getenv("CGP_NO_PACK") != nullptr;
+        ll = getenv("CGP_LL") != nullptr;           // opt-in: the left-looking panel route of small objects (smallchol.hpp)
         if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
         dag_min_nb = num("CGP_DAG_MIN_NB", 26);
@@ -443,6 +445,11 @@ int leaf_attr_once(cgp_handle* h) {
                                  (const void*)k_trsm_panel<8, 2>, (const void*)k_trsm_panel<16, 1>, (const void*)k_trsm_panel<16, 2>};
         for (const void* f : gen_fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS);
+        const void* ll_fns[] = {(const void*)k_ll_diag<0>, (const void*)k_ll_diag<1>, (const void*)k_ll_diag<2>,
+                                (const void*)k_ll_slab<4, 0>, (const void*)k_ll_slab<4, 1>, (const void*)k_ll_slab<4, 2>,
+                                (const void*)k_ll_slab<2, 0>, (const void*)k_ll_slab<2, 1>, (const void*)k_ll_slab<2, 2>};
+        for (const void* f : ll_fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LL_LDS_BYTES);
         err_dev[d] = e;
     });
     HIPCHK(err_dev[d]);
@@ -681,6 +688,46 @@ int factor_range(cgp_handle* h, Prob& P, long c0, long c1, long rlo, long R, boo
     CHK(launch_gemm(h, P.B, P.M + rs * ld + mid, ld, P.sM, P.M + rs * ld + c0, P.M + mid * ld + c0, ld, P.sM,
                     P.rend(R, mid) - rs, c1 - mid, mid - c0, chol, -1.0, 1.0, S, 0, 0, false, nullptr, 0, rvalid));
     return factor_range(h, P, mid, c1, rlo, R, chol);
+}
+
+// Left-looking factorisation of the small objects of P (smallchol.hpp): panel 0 by the diagonal-block and panel-solve kernels
+// (nothing to its left), every later panel by k_ll_diag + k_ll_slab.  gen: P.gen_on (first touch) or 0 (assembled input).
+int factor_ll(cgp_handle* h, Prob& P) {
+    const long ld = P.Np, nb = P.Np / NB;
+    hipStream_t S = h->stream;
+    const long Rv = P.rv > 0 ? P.rv : P.R;              // rows that carry data
+    CHK(factor_range(h, P, 0, NB, 0, P.R, true));        // panel 0: k_potrf_diag[_gen] + k_trsm_panel (all rows below)
+    GenSrc g = P.gen;
+    for (long p = 1; p < nb; ++p) {
+        const long c0 = p * NB;
+        {
+            StageScope sc(h, ST_POTRF);
+#define CGP_LL_DIAG(G) hipLaunchKernelGGL((k_ll_diag<G>), dim3(1, 1, P.B), dim3(LL_THREADS), LL_LDS_BYTES, S, P.M, ld, P.sM, (int)c0, P.wsW, P.sW, P.ldp, P.sLd, P.info, (int)p, g)
+            if (P.gen_on == 1) CGP_LL_DIAG(1); else if (P.gen_on == 2) CGP_LL_DIAG(2); else CGP_LL_DIAG(0);
+#undef CGP_LL_DIAG
+            HIPCHK(hipGetLastError());
+        }
+        StageScope sc(h, ST_TRSM);
+        const long mrows = P.Np - (c0 + NB);             // matrix rows below the diagonal tile: 128-row slabs
+        if (mrows > 0) {
+            const long slabs = mrows / NB;
+            const int xb = xcd_objects(h, P.B, slabs);
+            const dim3 gr((unsigned)slabs, 1, (unsigned)(xb ? round_up(P.B, 8) : P.B));
+#define CGP_LL_SLAB(MT, G, R0, NR) hipLaunchKernelGGL((k_ll_slab<MT, G>), gr, dim3(LL_THREADS), LL_LDS_BYTES, S, P.M, ld, P.sM, (int)c0, (int)(R0), P.wsW, P.sW, (int)p, (int)(NR), g, xb)
+            if (P.gen_on == 1) CGP_LL_SLAB(4, 1, c0 + NB, mrows); else if (P.gen_on == 2) CGP_LL_SLAB(4, 2, c0 + NB, mrows); else CGP_LL_SLAB(4, 0, c0 + NB, mrows);
+            HIPCHK(hipGetLastError());
+        }
+        const long trows = Rv - P.Np;                    // tall rows that carry data: 64-row slabs
+        if (trows > 0) {
+            const long slabs = (trows + 63) / 64;
+            const int xb = xcd_objects(h, P.B, slabs);
+            const dim3 gr((unsigned)slabs, 1, (unsigned)(xb ? round_up(P.B, 8) : P.B));
+            if (P.gen_on == 1) CGP_LL_SLAB(2, 1, P.Np, trows); else if (P.gen_on == 2) CGP_LL_SLAB(2, 2, P.Np, trows); else CGP_LL_SLAB(2, 0, P.Np, trows);
+#undef CGP_LL_SLAB
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return 0;
 }
 
 template <int DIM>
@@ -1204,8 +1251,19 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         HIPCHK(hipEventRecord(e0, h->stream));
         HIPCHK(hipStreamWaitEvent(h->stream2, e0, 0));
     }
+    // small objects of at least two panels, OPT-IN (CGP_LL=1): left-looking panels (smallchol.hpp), first touch or assembled input
+    // alike.  Measured (round 4, profiles/r04_c4_left_looking_route.log): 3.6 instead of 5.6 MB of HBM traffic per 512-point fit and
+    // +2 % with four handles in flight, but 0.52 against 0.41 ms per 128-object pass on ONE handle -- the update of the diagonal
+    // tile, inside wide update launches on the recursive route, becomes a 128-workgroup launch of its own -- so it is not the default
+    const bool ll = !to_dag && !h->trk.active && h->env.ll && h->env.bulk_cap == 0 && P.R < 2048 && P.Np >= 2 * NB &&
+                    P.tri_base < 0 && P.wrow0 < 0 && (fuse || P.zrow < 0) && P.pack == 1;
     if (to_dag) CHK(launch_dag(h, P));
-    else {
+    else if (ll) {
+        const int st = factor_ll(h, P);
+        P.gen_on = 0;
+        if (st < 0 && fuse) { P.zrow = -1; P.rv = 0; }
+        CHK(st);
+    } else {
         const int st = factor_range(h, P, 0, P.Np, 0, P.R, true);
         P.gen_on = 0;
         if (st < 0 && fuse) { P.zrow = -1; P.rv = 0; }

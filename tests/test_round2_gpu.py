@@ -624,6 +624,64 @@ def test_packed_small_objects_equal_their_own_tiles_and_the_oracle(dim, nmax, mo
     assert np.array_equal(rb[0][keep], outs[0][0][keep]) and np.array_equal(rb[2][keep], outs[0][2][keep])
 
 
+@pytest.mark.parametrize('dim', [1, 2])
+def test_left_looking_panel_route_of_small_objects(dim, monkeypatch):
+    """Round 4, opt-in (CGP_LL=1; csrc/smallchol.hpp): panels p >= 1 of a small object produced left-looking -- k_ll_diag (tile
+    (p, p) minus everything to its left in one K loop, then the factorisation in LDS) and k_ll_slab (a 128- or 64-row slab minus
+    everything to its left, through LDS into the panel solve, written once).  The sums of an entry run over the columns to its
+    left in one chain (the default route splits them by halves): every output within 1e-12 of the default route and at the
+    goldens' tolerances from the oracle; bit-identical between first-touch generation and assembled input, and between a batch
+    and the single fit of its first object."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(90 + dim)
+    ns = [512, 300, 257, 640, 1000, 130, 1800, 256]
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 19)
+        hyp = [0.9, 2.5]
+        kp = K.kernel_params_1d(hyp, 0.03)
+        kern = orc.rbf_kernel_1d
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (19, 2))
+        hyp = [1.0, 4.0, 5.0, 3.0]
+        kp = K.kernel_params_2d(hyp, nugget=0.03)
+        kern = orc.rbf_kernel_2d
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    outs = {}
+    for name, env in (('ll', {'CGP_LL': '1'}), ('ll_asm', {'CGP_LL': '1', 'CGP_NO_FUSED_ASM': '1'}), ('default', {})):
+        for k in ('CGP_LL', 'CGP_NO_FUSED_ASM'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, None, 0.03 ** 2)
+        dev.set_data(dim, xs[0], ys[0])
+        one = dev.fit(kp, diags[0], xn, None, 0.03 ** 2)
+        outs[name] = (r, one)
+        dev.close()
+    a, b, c = outs['ll'], outs['ll_asm'], outs['default']
+    assert not a[0][1].any()
+    for u, v in zip(a[0], b[0]):
+        assert np.array_equal(u, v)
+    assert a[0][0][0] == a[1][0] and np.array_equal(a[0][2][0], a[1][2]) and np.array_equal(a[0][3][0], a[1][3])
+    np.testing.assert_allclose(a[0][0], c[0][0], rtol=1e-12)
+    np.testing.assert_allclose(a[0][2], c[0][2], rtol=0, atol=1e-12 * np.abs(c[0][2]).max())
+    np.testing.assert_allclose(a[0][3], c[0][3], rtol=0, atol=1e-12)
+    for bq in (0, 4, 6):
+        Kc = kern(xs[bq], hyp, y_err=es[bq], nugget=0.03)
+        H = kern(xs[bq], hyp, new_x=xn)
+        amp = hyp[0] ** 2 if dim == 1 else 1.0
+        m0, v0, l0 = orc.fit_predict_cho(Kc, ys[bq], H, np.full(19, amp + 0.03 ** 2))
+        assert abs(l0 - a[0][0][bq]) <= 1e-11 * abs(l0)
+        np.testing.assert_allclose(a[0][2][bq], m0, rtol=0, atol=1e-9 * np.abs(ys[bq]).max())
+        np.testing.assert_allclose(a[0][3][bq], v0, rtol=0, atol=1e-9)
+
+
 def test_first_touch_generation_randomised_subset(monkeypatch):
     """A seeded ~6-s pass of tools/fused_stress.py: random dimension / sizes 3..1900 / batch 1..64 / prediction points 0..400 /
     mean / hyper-parameters (lxy = 0 and != 0, nugget, sigma^2 in the 2D train matrix or not), cgp_fit and cgp_batch_fit with
