@@ -218,3 +218,18 @@ def test_bench_launch_ranks_end_to_end(tmp_path, capfd):
     rc = bench.launch_ranks(3, script=str(script), argv=['die'])
     out = capfd.readouterr().out.strip()
     assert rc != 0 and out == '' and time.time() - t0 < 40
+
+
+def test_replayed_traffic_constant_belongs_to_the_device_code_at_head():
+    """`roofline.traffic` of the bench line is a replayed constant from a committed PMC pass (rocprofv3 cannot wrap the bench).  Every
+    traffic file records the sha256 of the device sources it was collected on (tools/pmc_traffic.py, tools/pmc_pass_traffic.py ->
+    bench.kernel_source_hash: kernels.hpp, rbfmath.hpp, dag.hpp, dag_tasks.hpp, smallchol.hpp); for every BASELINE configuration the
+    newest file must belong to the code at HEAD -- a kernel change without re-collecting the passes (tools/final_pass_r04.sh 3)
+    fails here, and the bench line's `roofline.traffic_source_current` says the same at run time."""
+    import bench
+    cur = bench.kernel_source_hash()
+    for wl, dag, nobj in (('c3', True, 8), ('c2', True, 16), ('c5', True, 4), ('c4', False, 128)):
+        path, rec = bench.traffic_file(wl, dag, nobj)
+        assert path is not None and os.path.basename(path).startswith('r04_'), (wl, path)
+        assert rec.get('kernel_sources_sha256') == cur, '%s was collected on other device sources: re-run tools/final_pass_r04.sh 3' % path
+        assert rec['traffic_bytes_per_launch'] > 0
