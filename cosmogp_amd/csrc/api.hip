@@ -374,7 +374,10 @@ int fail(cgp_handle* h, int code, const char* msg) {
 void drop_stale_staging(cgp_handle* h) {
     // (their asynchronous copies may still be in flight into / out of the pinned chunk this call is about to reuse: wait for
     // the stream first, then discard)
-    if (!h->pin_out.empty() || (!h->pin.empty() && h->pin.back().used != 0)) (void)stream_wait(h->stream);
+    if (!h->pin_out.empty() || (!h->pin.empty() && h->pin.back().used != 0)) {
+        (void)stream_wait(h->stream);
+        if (h->copy_stream) (void)stream_wait(h->copy_stream);       // (uploads of a pipelined cgp_batch_fit that failed half-way)
+    }
     h->pin_out.clear();
     if (!h->pin.empty()) h->pin.back().used = 0;
 }
@@ -876,6 +879,7 @@ int cgp_destroy(cgp_handle* h) {
     (void)hipSetDevice(h->device);
     drop_stale_staging(h);
     (void)stream_sync(h);
+    if (h->copy_stream) (void)stream_wait(h->copy_stream);
     for (auto& l : h->dag_lists) { free_buf(l.tasks); free_buf(l.state0); }
     DevBuf* all[] = {&h->csend, &h->crecv, &h->dstate, &h->dsticky, &h->bM, &h->bx, &h->br, &h->bdiag, &h->bxnew, &h->bws, &h->bldp, &h->binfo, &h->bns,
                      &h->bmean, &h->bmu, &h->bvar, &h->bscal, &h->bkp, &h->bC, &h->bout, &h->bns2, &h->bdiag2,
