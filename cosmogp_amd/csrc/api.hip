@@ -89,7 +89,7 @@ struct Prob {
     int kps = 0;         // 1: one KParams per object in bkp (cgp_sweep_loglik), 0: one shared set
     int gen_on = 0;      // 1 / 2: first-touch generation active for this factorisation (kernels.hpp, GenSrc), coordinates of 1 / 2 components
     long rv = 0;         // > 0: rows [rv, R) carry nothing (compact tall rows of a small object: cross rows, then the residual row(s), padded to 16)
-    int pack = 1, hs = 0, nobj = 0;   // PACKED small objects (kernels.hpp, GenSrc): B tiles of `pack` objects of <= hs points each, nobj objects in all
+    int pack = 1, hs = 0, nobj = 0; long sxo = 0;   // PACKED small objects (kernels.hpp, GenSrc): B tiles of `pack` objects of <= hs points each, nobj objects in all
     GenSrc gen;
     bool batch_api = false;   // bound by a batched entry point: always the launch-per-step route, whatever B, so that an object's
                               // numbers do not depend on how a caller chunks its batches (the single-launch route of cgp_fit
@@ -1225,7 +1225,7 @@ int device_fit_eager(cgp_handle* h, Prob& P, long m, bool has_mean) {
         g.x = P.x; g.sx = P.sx; g.xnew = P.xnew ? P.xnew : P.x; g.sxn = P.xnew ? P.sxn : 0; g.diag = P.diag; g.sd = P.sd;
         g.resid = P.r; g.sr = P.sr; g.ns = P.ns; g.kpp = (const KParams*)h->bkp.p; g.kps = P.kps;
         g.m = (int)m; g.Np = (int)P.Np;
-        g.pack = P.pack; g.hs = P.hs;
+        g.pack = P.pack; g.hs = P.hs; g.sxo = P.sxo;
         // compact tall rows (round 4): the residual row(s) sit right behind the cross rows, and everything from the next
         // multiple of 16 on is skipped by the solves (k_trsm_panel: nrows) and by the updates (k_gemm_nt: rows_valid) -- the
         // 20 real tall rows of a light curve predicted at 19 points used to ride as 64 through every solve and update
@@ -2217,8 +2217,8 @@ int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, con
 
 // The resident batch of objects of <= 64 points (Q: one 128-point slot per object) fitted with `pack` objects per tile.
 // *done = 1: results delivered; 0: some tile was not positive definite (nothing delivered, the caller runs the unpacked route).
-static int batch_fit_packed(cgp_handle* h, int dim, long B, const double* kp, const double* xnew, long m, const double* mean_new,
-                            double kss_noise, double* loglik, int32_t* info, double* mu, double* var, int* done) {
+static int batch_fit_packed(cgp_handle* h, int dim, long B, const double* kp, const double* xnew, long m, int xnew_per_object,
+                            const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu, double* var, int* done) {
     *done = 0;
     Prob& Q = h->Q;
     const int hs = Q.n <= 32 ? 32 : 64, pack = NB / hs;
@@ -2240,7 +2240,9 @@ static int batch_fit_packed(cgp_handle* h, int dim, long B, const double* kp, co
     CHK(ensure(h, h->qmu, (size_t)B * sOut * sizeof(double)));
     CHK(ensure(h, h->qvar, (size_t)B * sOut * sizeof(double)));
     CHK(upload_kp(h, kp, kss_noise));
-    CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)round_up(std::max(1l, m), 64) * dim));
+    const bool per_obj = xnew_per_object && m > 0;
+    if (per_obj) CHK(upload_padded(h, h->qxnew, xnew, (size_t)B * m * dim, (size_t)Bp * m * dim));      // [object][m] grids, tiles = `pack` of them
+    else CHK(upload_padded(h, h->qxnew, xnew, (size_t)m * dim, (size_t)round_up(std::max(1l, m), 64) * dim));
     CHK(upload_padded(h, h->qmean, mean_new, mean_new ? (size_t)m : 0, (size_t)sOut));
     hipLaunchKernelGGL(k_pack_small, dim3((unsigned)Bp), dim3(64), 0, h->stream, (const double*)h->qx.p, (const double*)h->qr.p,
                        (const double*)h->qdiag.p, (const int*)h->qns.p, (double*)h->pkx.p, (double*)h->pkr.p, (double*)h->pkd.p,
@@ -2250,7 +2252,7 @@ static int batch_fit_packed(cgp_handle* h, int dim, long B, const double* kp, co
     K.x = (double*)h->pkx.p; K.sx = NB * dim;
     K.r = (double*)h->pkr.p; K.sr = NB;
     K.diag = (double*)h->pkd.p; K.sd = NB;
-    K.xnew = (double*)h->qxnew.p; K.sxn = 0;
+    K.xnew = (double*)h->qxnew.p; K.sxn = per_obj ? pack * m * dim : 0; K.sxo = per_obj ? m * dim : 0;
     K.wsW = (double*)h->qws.p; K.sW = 8 * 256;
     K.ldp = (double*)h->qldp.p; K.sLd = 1;
     K.info = (int*)h->qinfo.p;
@@ -2425,7 +2427,7 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
         for (long b = 0; b < B; ++b) nmax = std::max<long>(nmax, ns[b]);
         const long chunk = pipe_chunk(round_up(std::max(1l, nmax), NB));
         // (objects of <= 64 points are packed several per tile instead, below: that halves their work, the pipeline only hides copies)
-        const bool packable = h && nmax <= 64 && !(xnew_per_object && m > 0) && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0;
+        const bool packable = h && nmax <= 64 && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0;
         if (chunk > 0 && B >= 2 * chunk && !packable) {
             CHK(begin_call(h));
             return batch_fit_pipelined(h, dim, B, ns, x, resid, diag, kp, xnew, m, xnew_per_object, mean_new, kss_noise, loglik,
@@ -2442,10 +2444,10 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
         return fail(h, CGP_E_ARG, "cgp_batch_fit: bad argument");
     h->last_packed = false;
-    if (Q.Np == NB && Q.n <= 64 && B >= 2 && !(xnew_per_object && m > 0) && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0) {
+    if (Q.Np == NB && Q.n <= 64 && B >= 2 && !h->env.no_pack && !h->env.no_fused_asm && h->env.bulk_cap == 0) {
         // objects of <= 64 (<= 32) points: two (four) per 128 x 128 tile as a block diagonal (kernels.hpp, GenSrc)
         int done = 0;
-        const int st = batch_fit_packed(h, dim, B, kp, xnew, m, mean_new, kss_noise, loglik, info, mu, var, &done);
+        const int st = batch_fit_packed(h, dim, B, kp, xnew, m, xnew_per_object, mean_new, kss_noise, loglik, info, mu, var, &done);
         if (st < 0 || done) return st;
         // (a tile met a non-positive pivot: its objects share the garbage behind it -- every object is refitted on its own tile)
     }

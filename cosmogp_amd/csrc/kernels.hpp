@@ -299,6 +299,7 @@ struct GenSrc {
     // entries are its objects' arrays back to back; ns has `pack` entries per tile; tall rows: pack x m cross rows (object
     // lo: rows Np + lo m ..., shared grid only), zero rows, then one residual row per object at zrow + lo.  hs = 0: unpacked.
     int pack = 1, hs = 0;
+    long sxo = 0;                    // packed tiles with one prediction grid PER OBJECT: stride of an object's grid inside its tile's block (0: shared grid)
 };
 struct GenObj { const double* x; const double* xnew; const double* diag; const double* resid; const int* ns; KParams kp; double yinv; int n; bool dvi; };
 // kind 0 train row, 1 identity padding, 2 cross row, 3 zero row, 4 residual; the row's object owns columns [c0, c0 + n)
@@ -329,10 +330,11 @@ __device__ __forceinline__ GenRow gen_row(const GenSrc& g, const GenObj& o, int 
         if (il < r.n) r.dg = o.kp.amp_train + (o.diag[i] + o.kp.nug2);
     } else if (i - g.Np < g.pack * g.m) {
         int t = i - g.Np;
-        if (g.hs) { const int lo = t / g.m; r.c0 = lo * g.hs; r.n = o.ns[lo]; t -= lo * g.m; }
+        const double* xn = o.xnew;
+        if (g.hs) { const int lo = t / g.m; r.c0 = lo * g.hs; r.n = o.ns[lo]; t -= lo * g.m; xn += (long)lo * g.sxo; }
         r.kind = 2;
-        r.vx = o.xnew[(long)t * DIM];
-        if (DIM == 2) r.vy = o.xnew[(long)t * DIM + 1];
+        r.vx = xn[(long)t * DIM];
+        if (DIM == 2) r.vy = xn[(long)t * DIM + 1];
     } else if (i >= g.zrow && i < g.zrow + g.pack) {
         r.kind = 4;
         if (g.hs) { const int lo = i - g.zrow; r.c0 = lo * g.hs; r.n = o.ns[lo]; }

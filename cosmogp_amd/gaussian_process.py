@@ -248,13 +248,27 @@ class Gaussian_process(object):
         if cached is not None and cached[0] == key:
             return cached[1]
         buckets = {}
+
+        def small_class(n):
+            return 0 if (grad or n > 64) else (1 if n > 32 else 2)
+        count = {}
         for sn in objs:
-            buckets.setdefault((len(self.y[sn]) + 127) // 128 * 128, []).append(sn)
+            c = small_class(len(self.y[sn]))
+            count[c] = count.get(c, 0) + 1
+        for sn in objs:
+            n = len(self.y[sn])
+            # (objects of at most 32 / 64 points get buckets of their own when there are enough of them: the library fits such a
+            # batch four / two objects per 128 x 128 tile, which it can only do when EVERY object of the call is that short)
+            small = small_class(n)
+            if count.get(small, 0) < 8:
+                small = 0
+            buckets.setdefault(((n + 127) // 128 * 128, -small), []).append(sn)
         chunks = []
-        for np_ in sorted(buckets, reverse=True):
+        for bkey in sorted(buckets, reverse=True):
+            np_ = bkey[0]
             rows = (3 * np_ + 128) if grad else (np_ + (int(m) + 1 + 127) // 128 * 128)
             per = max(1, min(MAX_BATCH_OBJECTS, int(BATCH_BYTES_LIMIT // (rows * np_ * 8))))
-            members = buckets[np_]
+            members = buckets[bkey]
             for lo in range(0, len(members), per):
                 chunks.append(members[lo:lo + per])
         self._chunks_cache = (key, chunks)

@@ -588,6 +588,7 @@ def test_packed_small_objects_equal_their_own_tiles_and_the_oracle(dim, nmax, mo
     es = [rng.uniform(0.05, 0.2, n) for n in ns]
     diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
     mean = 0.25 * np.ones(19)
+    xpo = rng.uniform(0., 30., (nobj, 23) if dim == 1 else (nobj, 23, 2))
     outs = []
     for packed in (True, False):
         monkeypatch.delenv('CGP_NO_PACK', raising=False)
@@ -598,7 +599,8 @@ def test_packed_small_objects_equal_their_own_tiles_and_the_oracle(dim, nmax, mo
         r2 = dev.batch_fit(dim, xs, ys, diags, kp, None, None, 0.)
         r3 = dev.batch_fit_resident(kp, xn, None, 0.)
         ms, _ = dev.bench_fit(3, stages=False)                  # the bench entry point replays the same (packed) pass
-        outs.append([r[0], r[1], r[2], r[3], r2[0], r3[0], r3[2], r3[3]])
+        r4 = dev.batch_fit(dim, xs, ys, diags, kp, xpo, None, 0.03 ** 2, xnew_per_object=True)   # one grid PER OBJECT
+        outs.append([r[0], r[1], r[2], r[3], r2[0], r3[0], r3[2], r3[3], r4[0], r4[2], r4[3]])
         dev.close()
     assert not outs[0][1].any()
     for a, b in zip(*outs):
@@ -680,6 +682,49 @@ def test_left_looking_panel_route_of_small_objects(dim, monkeypatch):
         assert abs(l0 - a[0][0][bq]) <= 1e-11 * abs(l0)
         np.testing.assert_allclose(a[0][2][bq], m0, rtol=0, atol=1e-9 * np.abs(ys[bq]).max())
         np.testing.assert_allclose(a[0][3][bq], v0, rtol=0, atol=1e-9)
+
+
+def test_packed_small_objects_through_the_classes(monkeypatch):
+    """The reference's own workflow on many short light curves (docs/notebook/1D_kernel_example_with_noise.ipynb; pull.py:51-66):
+    gaussian_process_nobject, prediction of every object ON ITS OWN GRID (new_binning=None, Gaussian_process.py:284-286) and on a
+    shared grid, joint log-likelihood -- with the objects packed two / four per tile and with one tile per object: the same
+    attributes bit for bit, and the oracle's numbers to the goldens' tolerances."""
+    import cosmogp_amd
+    from cosmogp_amd import _lib
+    rng = np.random.default_rng(314)
+    nobj = 31
+    xs = [np.sort(rng.uniform(-12., 42., int(n))) for n in rng.integers(8, 60, nobj)]
+    es = [rng.uniform(0.02, 0.1, len(x)) for x in xs]
+    ys = [0.5 * np.sin(x / 8.) + e * rng.standard_normal(len(x)) for x, e in zip(xs, es)]
+    grid = np.linspace(-12., 42., 19)
+    hyp = [0.5, 8.]
+    res = {}
+    for packed in (True, False):
+        monkeypatch.delenv('CGP_NO_PACK', raising=False)
+        if not packed:
+            monkeypatch.setenv('CGP_NO_PACK', '1')
+        dev = _lib.Device(0)
+        gp = cosmogp_amd.gaussian_process_nobject([y.copy() for y in ys], [x.copy() for x in xs], kernel='RBF1D',
+                                                  y_err=[e.copy() for e in es], device=dev)
+        gp.hyperparameters = np.array(hyp)
+        gp.get_prediction(new_binning=None, COV=False, svd_method=False)
+        own = ([p.copy() for p in gp.Prediction], [v.copy() for v in gp.variance])
+        gp.get_prediction(new_binning=grid, COV=False, svd_method=False)
+        shared = ([p.copy() for p in gp.Prediction], [v.copy() for v in gp.variance])
+        gp.compute_log_likelihood(gp.hyperparameters, svd_method=False)
+        res[packed] = (own, shared, float(gp.log_likelihood[0]))
+        dev.close()
+    a, b = res[True], res[False]
+    assert a[2] == b[2]
+    for k in range(nobj):
+        for q in (0, 1):
+            assert np.array_equal(a[0][q][k], b[0][q][k]) and np.array_equal(a[1][q][k], b[1][q][k])
+    ref = orc.predict(ys, xs, 'RBF1D', hyp, 0., es, new_binning=grid, svd_method=False)
+    for k in (0, 7, nobj - 1):
+        np.testing.assert_allclose(a[1][0][k], ref['prediction'][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(a[1][1][k], np.diag(ref['covariance'][k]), rtol=0, atol=1e-9)
+    ll = orc.total_log_likelihood(ys, xs, 'RBF1D', hyp, 0., es, [0.] * nobj, svd_method=False)
+    assert abs(a[2] - ll[0]) <= 1e-11 * abs(ll[0])
 
 
 def test_first_touch_generation_randomised_subset(monkeypatch):
