@@ -1331,6 +1331,7 @@ int device_fit(cgp_handle* h, Prob& P, long m, bool has_mean) {
         return device_fit_eager(h, P, m, has_mean);
     }
     if (h->graphs.size() >= 16) {        // small cache: drop the oldest (a pipelined batch holds one graph per chunk)
+        (void)stream_wait(h->stream);    // (it may be in flight: the earlier chunks of a pipelined call replay theirs on this stream)
         (void)hipGraphExecDestroy(h->graphs.front().exec);
         (void)hipGraphDestroy(h->graphs.front().graph);
         h->graphs.erase(h->graphs.begin());
