@@ -844,7 +844,7 @@ def main():
             callers = [adev] + [_lib.Device(local_rank) for _ in range(ncall - 1)]
             for c_ in callers:
                 c_.batch_fit(1, px, py, pd, wl['kp'], wl['xnew'], None, 0.)
-            reps_t = 16
+            reps_t = 48          # (16 calls per thread were as long as the threads' start-up: 180k-330k from run to run)
 
             def caller(c_):
                 for _ in range(reps_t):

@@ -930,8 +930,9 @@ int upload_kp(cgp_handle* h, const double* kp, double kss_noise) {
     k.amp_train = kp[0]; k.amp_cross = kp[1]; k.p0 = kp[2]; k.p1 = kp[3]; k.p2 = kp[4]; k.p3 = kp[5];
     k.nug2 = kp[6];
     k.kss_noise = kss_noise;
+    // (staged through the handle's pinned chunk by h2d: the stack copy may die, and the stream orders the copy behind every
+    // kernel that still reads the slot -- no synchronisation here: a batched API call pays ~15 us for each one)
     CHK(h2d(h, h->bkp.p, &k, sizeof(KParams)));
-    HIPCHK(stream_sync(h));
     return 0;
 }
 
@@ -2155,9 +2156,18 @@ int cgp_rbf(cgp_handle* h, int dim, const double* x, int64_t n, const double* xn
     return CGP_OK;
 }
 
+static int batch_set_data_impl(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
+                               const double* diag, bool sync_at_end);
+
 int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
                        const double* diag) {
     CHK(begin_call(h));
+    return batch_set_data_impl(h, dim, B, ns, x, resid, diag, true);
+}
+
+// sync_at_end = false: the caller (cgp_batch_fit with host data) goes on queueing on the same stream and synchronises once
+static int batch_set_data_impl(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const double* x, const double* resid,
+                               const double* diag, bool sync_at_end) {
     if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid)
         return fail(h, CGP_E_ARG, "cgp_batch_set_data: bad argument");
     long nmax = 0;
@@ -2211,7 +2221,7 @@ int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns, con
         for (long b = 0; b < B; ++b) hn[b] = (int)ns[b];
         HIPCHK(hipMemcpyAsync(h->qns.p, hn, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(stream_sync(h));       // the staging chunks are recycled by the next call
+    if (sync_at_end) HIPCHK(stream_sync(h));       // the staging chunks are recycled by the next call
     h->have_batch = true;
     return CGP_OK;
 }
@@ -2435,11 +2445,12 @@ int cgp_batch_fit(cgp_handle* h, int dim, int64_t B, const int64_t* ns, const do
                                        info, mu, var, chunk);
         }
     }
-    if (x || resid) {          // data given: upload it first; x == resid == NULL: use the resident batch
-        int st = cgp_batch_set_data(h, dim, B, ns, x, resid, diag);
+    CHK(begin_call(h));
+    if (x || resid) {          // data given: upload it first (no synchronisation of its own); x == resid == NULL: use the resident batch
+        pin_reserve(h, (size_t)B * 130 * (dim + 2) * sizeof(double));       // (a first guess; pin_alloc grows it)
+        int st = batch_set_data_impl(h, dim, B, ns, x, resid, diag, false);
         if (st != 0) return st;
     }
-    CHK(begin_call(h));
     Prob& Q = h->Q;
     if (!h->have_batch) return fail(h, CGP_E_STATE, "cgp_batch_fit: no resident batch (call cgp_batch_set_data)");
     if (!kp || m < 0 || (m > 0 && (!xnew || !mu)) || B != Q.B || dim != Q.dim)
