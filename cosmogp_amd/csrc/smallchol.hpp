@@ -217,31 +217,21 @@ __global__ __launch_bounds__(LL_THREADS) void k_ll_diag(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_ll_slab: rows [r0 + TM bx, + TM) of panel p = c0 / 128 >= 1, TM = 32 MT (128: matrix rows, 64: tall rows), grid
-// (slabs, 1, B) or its XCD-affine form.  nrows: rows of the launch that carry data (a last slab may be part empty).
+// One slab of one panel: rows [row0, row0 + TM) (the first `valid` carry data), panel p = c0 / 128, TM = 32 MT.
+//   S = [generated | loaded] - sum_{k < p} L(rows, k) L(p, k)^T in registers (one K loop of depth c0), through LDS into the
+//   panel solve's layout (wave w: rows 16 w .. 16 w + 15, all 128 columns), L_pp + its T^-T blocks staged, X = S L_pp^-T
+//   (the K4 code: kernels.hpp k_trsm_panel), written once.  Every thread of the workgroup calls this; no thread leaves early
+//   (k_ll_tall walks the panels in a loop).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT, int GEN>
-__global__ __launch_bounds__(LL_THREADS) void k_ll_slab(
-    double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW, long sW, int blk, int nrows,
-    GenSrc g, int xcdB) {
+__device__ __forceinline__ void ll_slab_body(double* __restrict__ M, long ld, int c0, int row0, int valid,
+                                             const double* __restrict__ wsW, const GenSrc& g, int b, double* smem, const double* etab) {
     constexpr int TM = 32 * MT;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ __attribute__((aligned(16))) double etab[GEN != 0 ? 128 : 2];
     double* Ls = smem;                               // S tile [TM][CGP_LDA], then L_pp [128][CGP_LDA] (strictly-lower tiles)
     double* Ws = smem + CGP_NB * CGP_LDA;            // [8][16][16]
-    int b = blockIdx.z, bx = blockIdx.x;
-    if (xcdB > 0 && !xcd_affine(b, bx, xcdB)) return;
-    M += (long)b * sM;
-    wsW += (long)b * sW + (long)blk * (8 * 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / 4, wn = wave % 4;
     const int lr = lane & 15, lq = lane >> 4, lu = lane & 3, lb = (lane >> 2) & 3, lp = lu;
-    const int row0 = r0 + bx * TM;
-    const int valid = min(TM, nrows - bx * TM);      // rows of this slab that carry data
-    if (GEN != 0) {
-        rbf_stage_table(etab);
-        __syncthreads();
-    }
     const bool wave_on = wm * (16 * MT) < valid;
     double acc[MT][8];
     ll_init_acc<MT, GEN>(acc, M + (long)row0 * ld + c0, ld, g, b, row0, c0, etab, wave_on);
@@ -256,7 +246,7 @@ __global__ __launch_bounds__(LL_THREADS) void k_ll_slab(
                 *(d2*)(Ls + (r_ + 16 * i) * CGP_LDA + c_ + 8 * jj) = (d2){-acc[i][2 * jj], -acc[i][2 * jj + 1]};
     }
     __syncthreads();
-    const bool has_rows = wave * 16 < valid;         // (wave < TM / 16 follows)
+    const bool has_rows = wave * 16 < valid && wave * 16 < TM;
     double S[8][4];
     if (has_rows) {
         const double* sp = Ls + (wave * 16 + 4 * lb + lq) * CGP_LDA + 4 * lu;
@@ -289,7 +279,7 @@ __global__ __launch_bounds__(LL_THREADS) void k_ll_slab(
         for (int q = 0; q < 2; ++q) *(d2*)(Ws + 2 * (tid + q * LL_THREADS)) = w[q];
     }
     __syncthreads();
-    if (!has_rows) return;
+    if (has_rows) {
     // X = S L_pp^-T, right-looking over the eight 16-column tiles (the K4 code: kernels.hpp k_trsm_panel)
     const int xg = wave < 6 ? 0 : 1, xt = wave - 6 * xg;
     double* Xs = Ls + xg * 16 * CGP_LDA + 16 + 18 * xt;
@@ -337,4 +327,25 @@ __global__ __launch_bounds__(LL_THREADS) void k_ll_slab(
             }
         }
     }
+    }
+}
+
+// k_ll_slab: rows [r0 + TM bx, + TM) of panel p = c0 / 128 >= 1, TM = 32 MT (128: matrix rows, 64: tall rows), grid
+// (slabs, 1, B) or its XCD-affine form.  nrows: rows of the launch that carry data (a last slab may be part empty).
+template <int MT, int GEN>
+__global__ __launch_bounds__(LL_THREADS) void k_ll_slab(
+    double* __restrict__ M, long ld, long sM, int c0, int r0, const double* __restrict__ wsW, long sW, int blk, int nrows,
+    GenSrc g, int xcdB) {
+    constexpr int TM = 32 * MT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ __attribute__((aligned(16))) double etab[GEN != 0 ? 128 : 2];
+    int b = blockIdx.z, bx = blockIdx.x;
+    if (xcdB > 0 && !xcd_affine(b, bx, xcdB)) return;
+    M += (long)b * sM;
+    wsW += (long)b * sW + (long)blk * (8 * 256);
+    if (GEN != 0) {
+        rbf_stage_table(etab);
+        __syncthreads();
+    }
+    ll_slab_body<MT, GEN>(M, ld, c0, r0 + bx * TM, min(TM, nrows - bx * TM), wsW, g, b, smem, etab);
 }
