@@ -221,7 +221,7 @@ __global__ __launch_bounds__(LL_THREADS) void k_ll_diag(
 //   S = [generated | loaded] - sum_{k < p} L(rows, k) L(p, k)^T in registers (one K loop of depth c0), through LDS into the
 //   panel solve's layout (wave w: rows 16 w .. 16 w + 15, all 128 columns), L_pp + its T^-T blocks staged, X = S L_pp^-T
 //   (the K4 code: kernels.hpp k_trsm_panel), written once.  Every thread of the workgroup calls this; no thread leaves early
-//   (k_ll_tall walks the panels in a loop).
+//   (so that a caller may walk several panels in a loop).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MT, int GEN>
 __device__ __forceinline__ void ll_slab_body(double* __restrict__ M, long ld, int c0, int row0, int valid,
