@@ -49,7 +49,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     # (the device code of every kernel a fit launches; api.hip -- host orchestration -- is left out: it changes with every
     # entry point added, its schedule constants are recorded in the bench line itself)
-    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp', 'smallchol.hpp'):
+    for f in ('kernels.hpp', 'rbfmath.hpp', 'dag.hpp', 'dag_tasks.hpp', 'smallchol.hpp', 'potrf4.hpp'):
         with open(os.path.join(ROOT, 'cosmogp_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -99,7 +99,8 @@ def make_workload(name, rank=0, obj=0, nobj=128):
         hyp = [0.5, 8.]
         return dict(dim=1, n=n, m=m, B=B, xs=xs, ys=ys, es=es, xnew=np.linspace(-12., 42., m), hyp=hyp,
                     kp=K.kernel_params_1d(hyp),
-                    label='%d x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3]: 1024 over 8 GPUs)' % B)
+                    label='%d x 1D light-curve GPs N=512 M=19 per GPU per step (BASELINE config[3]: 1024 light curves; with the default '
+                          '512 per pass x 2 handles all 1024 are in flight on the GPU)' % B)
     if name == 'c5':
         rng = np.random.default_rng(5)                      # same field on every rank, pairs differ
         n = 16384
@@ -363,7 +364,7 @@ def other_configs(local_rank):
     constant with its currency flag.  A child that fails is reported, never fatal."""
     import subprocess
     out = {}
-    for name, steps, warm in (('c2', 10, 2), ('c4', 400, 40), ('c5', 6, 1)):
+    for name, steps, warm in (('c2', 10, 2), ('c4', 200, 20), ('c5', 6, 1)):
         cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--gpus', '1', '--no-cpu-baseline',
                '--steps', str(steps), '--warmup', str(warm)]
         env = dict(os.environ, COSMOGP_DEVICE=str(local_rank), CGP_BENCH_NO_CONFIGS='1')
@@ -493,7 +494,7 @@ class FileComm(object):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 10; c4: 200 -- its step is 0.35 ms)')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 10; c4: 200 -- its step is 1.1 ms)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps before them (default 2; c4: 20)')
     ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -555,7 +556,9 @@ def main():
                 print('rank %d: RCCL reports %d ranks, launched with %d' % (rank, rccl_ranks, world), file=sys.stderr)
                 sys.exit(3)
             collective = 'RCCL inside the library (cgp_comm_*: ncclAllGather / ncclAllReduce on the handle\'s stream)'
-    wl = make_workload(args.workload, rank, nobj=int(os.environ.get('CGP_BENCH_C4_NOBJ', '128')))
+    # config 4 on one GPU is the WHOLE configuration (1024 light curves) in flight: 512 per pass x 2 handles; every further
+    # rank brings its own 1024 (weak scaling: the per-GPU work does not change with N)
+    wl = make_workload(args.workload, rank, nobj=int(os.environ.get('CGP_BENCH_C4_NOBJ', '512')))
     batched = 'B' in wl
     # Batches of objects with >= 16 tile columns (N >= 2048) are factored by ONE persistent launch per group of objects
     # (csrc/dag.hpp, several leaf lanes + one interleaved task list); smaller objects and CGP_NO_DAG_BATCH=1 take one launch
@@ -569,7 +572,7 @@ def main():
     else:
         # objects per launch sequence
         lock = (16 if (dag_batch and wl['n'] <= 4096) else 8) if args.batch < 0 else max(1, args.batch)
-    nstreams = args.streams if args.streams > 0 else (4 if batched else ((1 if dag_batch else 2) if lock > 1 else 4))
+    nstreams = args.streams if args.streams > 0 else ((2 if wl['B'] >= 512 else 4) if batched else ((1 if dag_batch else 2) if lock > 1 else 4))
     if 'sweep' in wl and args.streams <= 0:
         nstreams = 1 if lock > 1 else 4
     # Independent fits are the unit of this path (objects, candidates): with several in flight the

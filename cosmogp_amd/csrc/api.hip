@@ -5,6 +5,7 @@
 #include "dag.hpp"
 #include "dag_tasks.hpp"
 #include "smallchol.hpp"
+#include "potrf4.hpp"
 #include "spline.hpp"
 #include "../../include/cosmogp_hip.h"
 
@@ -107,8 +108,8 @@ enum Stage { ST_ASM_K = 0, ST_POTRF, ST_TRSM, ST_GEMM, ST_ASM_H, ST_FINISH, ST_G
 struct CgpEnv {
     int bulk_cap = 0, k4_waves = 0, jac_inner = 1;
     double jac_tol = 1.0, eig_cond_max = 1e10;
-    long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0;
-    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false, no_pack = false, ll = false;
+    long bigtile = GEMM_BIG_TILE_THRESHOLD, gemm_chunk = 0, potrf4_min = 512;
+    bool no_graph = false, lookahead = false, stream2 = false, debug = false, jac_no_small = false, jac_no_lowrank = false, eig_no_chol = false, no_dag = false, no_fused_asm = false, no_xcd = false, no_pack = false, ll = false, no_potrf4 = false;
     // single object: the single launch from dag_min_nb tile columns on (below, the launch-per-step graph is 3-10 % faster:
     // tools/chol_rate.py); depth / window / dmax 0 = by the tile count (dag_list)
     long dag_min_nb = 26, dag_timeout_ms = 4000, dag_grid = 0, dag_depth = 0, dag_window = 0, dag_fill = 70,
@@ -136,6 +137,8 @@ struct CgpEnv {
         no_fused_asm = getenv("CGP_NO_FUSED_ASM") != nullptr;
         no_xcd = getenv("CGP_NO_XCD") != nullptr;
         no_pack = getenv("CGP_NO_PACK") != nullptr;
+        no_potrf4 = getenv("CGP_NO_POTRF4") != nullptr;
+        potrf4_min = num("CGP_POTRF4_MIN", 512);
         ll = getenv("CGP_LL") != nullptr;           // opt-in: the left-looking panel route of small objects (smallchol.hpp)
         if (const char* v = getenv("CGP_EIG_COND_MAX")) eig_cond_max = atof(v);
         no_dag = getenv("CGP_NO_DAG") != nullptr;
@@ -453,6 +456,9 @@ int leaf_attr_once(cgp_handle* h) {
                                 (const void*)k_ll_slab<2, 0>, (const void*)k_ll_slab<2, 1>, (const void*)k_ll_slab<2, 2>};
         for (const void* f : ll_fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LL_LDS_BYTES);
+        const void* p4_fns[] = {(const void*)k_potrf_diag4<0>, (const void*)k_potrf_diag4<1>, (const void*)k_potrf_diag4<2>};
+        for (const void* f : p4_fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P4_LDS_BYTES);
         err_dev[d] = e;
     });
     HIPCHK(err_dev[d]);
@@ -569,6 +575,22 @@ hipEvent_t next_fork_event(cgp_handle* h) {
 
 int launch_potrf(cgp_handle* h, Prob& P, long c0, hipStream_t stream) {
     StageScope sc(h, ST_POTRF);
+    if (P.B >= h->env.potrf4_min && !h->env.no_potrf4) {
+        // large batches: four objects' blocks per workgroup, their pivot chains side by side (potrf4.hpp; same bits as k_potrf_diag).
+        // A workgroup lasts 69 us against 36 at a quarter of the workgroups: half the CU time, twice the latency of the launch.  Worth it
+        // from ~512 objects per launch on: 512 x 2 handles 426k -> 456k fits/s, 512 x 4 437k -> 467k, 1024 on one handle 399k -> 441k,
+        // 1024 x 2 422k -> 470k; 256 x 4 handles 426k -> 446k but a lone 256-object pass (the chunks of a pipelined API call) gets
+        // SLOWER, 128 x 4: 418k -> 413k (profiles/r04_c4_potrf4.log).  CGP_POTRF4_MIN: objects per launch from which it is used (512)
+        GenSrc g = P.gen;
+        g.row0 = 0; g.col0 = 0;
+        const dim3 gr((unsigned)((P.B + 3) / 4));
+        const int gen = (P.gen_on && c0 == 0) ? P.gen_on : 0;
+#define CGP_P4(G) hipLaunchKernelGGL((k_potrf_diag4<G>), gr, dim3(512), P4_LDS_BYTES, stream, P.M, P.Np, P.sM, (int)c0, P.wsW, P.sW, P.ldp, P.sLd, P.info, (int)(c0 / NB), g, (int)P.B)
+        if (gen == 1) CGP_P4(1); else if (gen == 2) CGP_P4(2); else CGP_P4(0);
+#undef CGP_P4
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (P.gen_on && c0 == 0) {
         GenSrc g = P.gen;
         g.row0 = 0; g.col0 = 0;

@@ -727,6 +727,53 @@ def test_packed_small_objects_through_the_classes(monkeypatch):
     assert abs(a[2] - ll[0]) <= 1e-11 * abs(ll[0])
 
 
+@pytest.mark.parametrize('dim', [1, 2])
+def test_four_blocks_per_workgroup_factorisation_bit_identical(dim, monkeypatch):
+    """Round 4 (csrc/potrf4.hpp): in large batches one workgroup factors the 128 x 128 diagonal blocks of FOUR objects, their pivot
+    chains side by side, as a two-level blocked factorisation on 64 x 64 quarters.  Every entry receives the operations it receives
+    in k_potrf_diag, in the same order: every output of a batched fit -- ragged lengths over 1-6 panels, an object count that is
+    not a multiple of 4, first touch and assembled input, prediction rows -- equals the one-block-per-workgroup kernel
+    (CGP_NO_POTRF4=1) bit for bit; a non-positive-definite object reports the same pivot and leaves the others alone."""
+    from cosmogp_amd import _lib
+    from cosmogp_amd import kernel as K
+    rng = np.random.default_rng(700 + dim)
+    nobj = 43
+    ns = [int(v) for v in rng.integers(100, 760, nobj)]
+    ns[0], ns[1], ns[2] = 512, 128, 129
+    if dim == 1:
+        xs = [np.sort(rng.uniform(0., 30., n)) for n in ns]
+        ys = [np.sin(x / 3.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., 19)
+        kp = K.kernel_params_1d([0.9, 2.5], 0.03)
+    else:
+        xs = [rng.uniform(0., 30., (n, 2)) for n in ns]
+        ys = [np.sin(x[:, 0] / 3.) * np.cos(x[:, 1] / 4.) + 0.1 * rng.standard_normal(len(x)) for x in xs]
+        xn = rng.uniform(0., 30., (19, 2))
+        kp = K.kernel_params_2d([0.9, 4.0, 5.0, 3.0], nugget=0.03)
+    es = [rng.uniform(0.05, 0.2, n) for n in ns]
+    diags = [K.diag_term(len(y), e, 0., 0.) for y, e in zip(ys, es)]
+    bad = [d.copy() for d in diags]
+    bad[5][ns[5] // 2] = -10.                                   # a negative "variance": object 5 is not positive definite
+    outs = []
+    for four, fused in ((True, True), (False, True), (True, False)):
+        for k in ('CGP_NO_POTRF4', 'CGP_POTRF4_MIN', 'CGP_NO_FUSED_ASM'):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv('CGP_POTRF4_MIN', '8') if four else monkeypatch.setenv('CGP_NO_POTRF4', '1')
+        if not fused:
+            monkeypatch.setenv('CGP_NO_FUSED_ASM', '1')
+        dev = _lib.Device(0)
+        r = dev.batch_fit(dim, xs, ys, diags, kp, xn, None, 0.01)
+        r2 = dev.batch_fit(dim, xs, ys, diags, kp, None, None, 0.)
+        rb = dev.batch_fit(dim, xs, ys, bad, kp, xn, None, 0.01)
+        keep = np.arange(nobj) != 5
+        outs.append([r[0], r[1], r[2], r[3], r2[0], rb[1], rb[0][keep], rb[2][keep]])
+        dev.close()
+    assert not outs[0][1].any() and outs[0][5][5] > 0 and not np.delete(outs[0][5], 5).any()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 def test_first_touch_generation_randomised_subset(monkeypatch):
     """A seeded ~6-s pass of tools/fused_stress.py: random dimension / sizes 3..1900 / batch 1..64 / prediction points 0..400 /
     mean / hyper-parameters (lxy = 0 and != 0, nugget, sigma^2 in the 2D train matrix or not), cgp_fit and cgp_batch_fit with
