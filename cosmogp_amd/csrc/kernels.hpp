@@ -816,7 +816,10 @@ __global__ __launch_bounds__(64 * K4W) void k_trsm_panel(
 //   tri = 1: only tiles on/below the diagonal of the (square-tiled) C region are launched:
 //   tile rows [0, nc) form the triangle, rows [nc, nr) are full.
 // ------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN> struct MT_OK_FOR_GEN { static constexpr bool value = (TM / WM / 16) * (TN / WN / 4) <= 8; };
+#ifndef CGP_EARLYC_MAX
+#define CGP_EARLYC_MAX 8
+#endif
+template <int TM, int TN, int WM, int WN> struct MT_OK_FOR_GEN { static constexpr bool value = (TM / WM / 16) * (TN / WN / 4) <= CGP_EARLYC_MAX; };
 // KB = stage depth (16 or 32); LDS row stride KB + 2 doubles keeps every row 16-B aligned
 // ABLATE (diagnostic builds only, tools/gemm_ablate.hip): 1 = no global loads inside the loop,
 // 2 = additionally no LDS fragment reads inside the loop (wrong results, timing only)
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
     double* Cg = C + (long)(ti * TM + wm * (TM / WM) + ((lane >> 2) & 3) * 4 + lq) * ldc + tj * TN + wn * (TN / WN) + lp;
     // Small wave tiles (the thin updates): the C values are fetched BEFORE the K loop, so the read-modify-write
     // latency of the epilogue hides under it (8 more registers; the large form keeps its 4 waves per SIMD instead)
-    constexpr bool EARLYC = (MT * NJ <= 8);
+    constexpr bool EARLYC = (MT * NJ <= CGP_EARLYC_MAX);
     double cv[EARLYC ? MT : 1][EARLYC ? NJ : 1];
     if (GEN != 0) {
         // (computed below, once the first two stage loads are on their way)
