@@ -37,4 +37,5 @@ else
   ./tools/pmc_run.sh final/r04_pmc_traffic_c2_dagbatch 16 k_chol_dag --workload c2 && echo "traffic c2 done"
   ./tools/pmc_run.sh final/r04_pmc_traffic_c5_dagbatch 4 k_chol_dag --workload c5 && echo "traffic c5 done"
   bash tools/r04_pmc_c4.sh final/r04_pmc_traffic_c4 && echo "traffic c4 done"
+  ./tools/pmc_run.sh final/r04_pmc_traffic_c3_single 1 k_chol_dag --batch 1 --streams 1 && echo "traffic c3 single done"
 fi
