@@ -290,6 +290,8 @@ int fail(cgp_handle* h, int code, const char* msg);
 // asynchronous copy; device -> host = asynchronous copy into a chunk, delivered to the caller's array by stream_sync
 // after the stream has been POLLED to completion.  Larger transfers (N x N matrices) keep the direct path.
 constexpr size_t PIN_MAX = 8u << 20;
+constexpr size_t PIN_KEEP_MAX = 256u << 20;      // a staging chunk larger than this is returned after the call that needed it
+constexpr long CGP_MAX_BATCH = 65535;            // objects per batch: the object index travels in a grid dimension
 
 void* pin_alloc(cgp_handle* h, size_t bytes) {
     bytes = (bytes + 63) & ~(size_t)63;
@@ -364,6 +366,10 @@ hipError_t stream_sync(cgp_handle* h) {
         h->pin.erase(h->pin.begin(), h->pin.end() - 1);
     }
     if (!h->pin.empty()) h->pin.back().used = 0;
+    if (!h->pin.empty() && h->pin.back().cap > PIN_KEEP_MAX) {      // (pinned memory is the host's, not the library's to keep)
+        (void)hipHostFree(h->pin.back().p);
+        h->pin.pop_back();
+    }
     return e;
 }
 
@@ -2192,6 +2198,7 @@ static int batch_set_data_impl(cgp_handle* h, int dim, int64_t B, const int64_t*
                                const double* diag, bool sync_at_end) {
     if ((dim != 1 && dim != 2) || B <= 0 || !ns || !x || !resid)
         return fail(h, CGP_E_ARG, "cgp_batch_set_data: bad argument");
+    if (B > CGP_MAX_BATCH) return fail(h, CGP_E_ARG, "cgp_batch_set_data: more than 65535 objects in one batch (the object index is a grid dimension)");
     long nmax = 0;
     for (long b = 0; b < B; ++b) {
         if (ns[b] <= 0) return fail(h, CGP_E_ARG, "cgp_batch_set_data: ns[b] <= 0");
@@ -2334,6 +2341,7 @@ static int batch_fit_pipelined(cgp_handle* h, int dim, long B, const int64_t* ns
                                const double* mean_new, double kss_noise, double* loglik, int32_t* info, double* mu, double* var,
                                long chunk) {
     Prob& Q = h->Q;
+    if (B > CGP_MAX_BATCH) return fail(h, CGP_E_ARG, "cgp_batch_fit: more than 65535 objects in one batch (the object index is a grid dimension)");
     long nmax = 0;
     std::vector<long> off((size_t)B + 1, 0);
     for (long b = 0; b < B; ++b) {

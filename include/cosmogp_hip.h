@@ -171,7 +171,9 @@ int cgp_fit_fetch(cgp_handle* h, int which, double* out);
  * the new_binning of Gaussian_process.py:287-289) or B grids of m points each
  * (xnew_per_object = 1; leave-one-out of cosmogp/pull.py:75-90) -- may be NULL (m = 0).
  * mean_new: m doubles shared by all objects or NULL.
- * Outputs: loglik[B], info[B] (0 or first bad pivot), mu[B*m], var[B*m] (may be NULL). */
+ * Outputs: loglik[B], info[B] (0 or first bad pivot), mu[B*m], var[B*m] (may be NULL).
+ * B <= 65535 per call (the object index is a grid dimension): CGP_E_ARG beyond; the Python classes cut longer
+ * lists into several calls (gaussian_process.MAX_BATCH_OBJECTS). */
 int cgp_batch_set_data(cgp_handle* h, int dim, int64_t B, const int64_t* ns,
                        const double* x, const double* resid, const double* diag);
 /* x == resid == NULL: fit the batch left resident by cgp_batch_set_data (B, dim must match; ns, diag

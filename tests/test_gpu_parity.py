@@ -983,6 +983,19 @@ def test_abi_status_codes(cg):
         assert lib.cgp_sweep_loglik(h, 0, kp, None, ctypes.byref(ll), None) == -1
         assert lib.cgp_sweep_loglik(h, 257, kp, None, ctypes.byref(ll), None) == -1
         assert lib.cgp_fit(h, None, None, None, 0, None, 0., ctypes.byref(ll), None, None, None) == -1
+        # more objects than a grid dimension holds (both routes of cgp_batch_fit: the pipelined one checks for itself)
+        nbig = 65536
+        ns = (ctypes.c_int64 * nbig)(*([4] * nbig))
+        xb = (ctypes.c_double * (4 * nbig))()
+        llb = (ctypes.c_double * nbig)()
+        assert lib.cgp_batch_set_data(h, 1, nbig, ns, xb, xb, None) == -1 and b'65535' in lib.cgp_last_error(h)
+        assert lib.cgp_batch_fit(h, 1, nbig, ns, xb, xb, None, kp, None, 0, 0, None, 0., llb, None, None, None) == -1
+        assert b'65535' in lib.cgp_last_error(h)
+        ns65 = (ctypes.c_int64 * nbig)(*([65] * nbig))            # (too long to be packed: the pipelined route)
+        x65 = (ctypes.c_double * (65 * nbig))()
+        assert lib.cgp_batch_fit(h, 1, nbig, ns65, x65, x65, None, kp, None, 0, 0, None, 0., llb, None, None, None) == -1
+        assert b'65535' in lib.cgp_last_error(h)
+        del x65, xb
         # a valid call still works on the same handle afterwards ...
         diag = (ctypes.c_double * 4)(0.1, 0.1, 0.1, 0.1)
         assert lib.cgp_fit(h, kp, diag, None, 0, None, 0., ctypes.byref(ll), None, None, None) == 0
