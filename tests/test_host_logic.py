@@ -150,6 +150,26 @@ def test_batch_chunks_respect_grid_and_memory_limits(monkeypatch):
     assert max(len(c) for c in gp._batch_chunks(list(range(100)), m=0)) == 45
 
 
+def test_batch_chunks_give_short_objects_buckets_of_their_own():
+    """Objects of <= 32 / <= 64 points are fitted four / two per tile when EVERY object of a call is that short
+    (csrc/api.hip, batch_fit_packed): the host side therefore gives each class its own launch sequence -- from 8
+    objects of the class on; fewer stay with the other 128-point objects (one call less)."""
+    import cosmogp_amd
+    from fake_device import FakeDevice
+    lens = [20] * 9 + [50] * 8 + [100] * 3 + [300] * 2
+    gp = cosmogp_amd.gaussian_process_nobject([np.zeros(n) for n in lens], [np.arange(float(n)) for n in lens],
+                                              kernel='RBF1D', device=FakeDevice())
+    chunks = gp._batch_chunks(list(range(len(lens))))
+    assert sorted(map(sorted, chunks)) == sorted([list(range(0, 9)), list(range(9, 17)), [17, 18, 19], [20, 21]])
+    lens = [20] * 7 + [50] * 8 + [100] * 3            # seven of the shortest class: they join the plain 128-point bucket
+    gp = cosmogp_amd.gaussian_process_nobject([np.zeros(n) for n in lens], [np.arange(float(n)) for n in lens],
+                                              kernel='RBF1D', device=FakeDevice())
+    chunks = gp._batch_chunks(list(range(len(lens))))
+    assert sorted(map(sorted, chunks)) == sorted([list(range(0, 7)) + [15, 16, 17], list(range(7, 15))])
+    # the gradient needs the identity rows of every object: no packing, one bucket per padded size
+    assert sorted(map(sorted, gp._batch_chunks(list(range(len(lens))), grad=True))) == [list(range(18))]
+
+
 def test_bench_file_fallback_communicator(tmp_path):
     """bench.py's stand-in for the case that the RCCL communicator cannot be created: barrier / all-gather / max over
     files, three processes."""
