@@ -823,8 +823,11 @@ template <int TM, int TN, int WM, int WN> struct MT_OK_FOR_GEN { static constexp
 // KB = stage depth (16 or 32); LDS row stride KB + 2 doubles keeps every row 16-B aligned
 // ABLATE (diagnostic builds only, tools/gemm_ablate.hip): 1 = no global loads inside the loop,
 // 2 = additionally no LDS fragment reads inside the loop (wrong results, timing only)
+#ifndef CGP_SMALL_WPE
+#define CGP_SMALL_WPE 1      // minimum waves per SIMD asked of the compiler for the 64 x 64 form (1 = no constraint; scan: 4.3)
+#endif
 template <int TM, int TN, int WM, int WN, int KB, int ABLATE = 0, int GEN = 0>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt(
+__global__ __launch_bounds__(64 * WM * WN, (TM == 64 && TN == 64) ? CGP_SMALL_WPE : 1) void k_gemm_nt(
     double* __restrict__ C, long ldc, long sC, const double* __restrict__ A, const double* __restrict__ B,
     long ld, long sAB, int K, int nr, int nc, int tri, double alpha, double beta, int tile_skip, int ktri,
     int tile_end = 0, const int2* __restrict__ tab = nullptr, int ntab = 0, GenSrc g = GenSrc(), int xcdB = 0,
