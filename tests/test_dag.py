@@ -388,3 +388,13 @@ def test_dag_concurrent_launches_subset(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     count, bad, errors = _tool('dag_concurrent_stress').run_concurrent(6., 4, sizes=(2600, 1300, 900, 2050))
     assert not errors and not any(bad) and min(count) >= 3, (count, bad, errors)
+
+
+def test_mixed_entry_points_concurrently_subset(monkeypatch):
+    """Six host threads, a handle each, ~5 s, DIFFERENT entry points at once: a pipelined cgp_batch_fit, packed objects of tens
+    of points, a single-launch fit, 512 light curves per call (four diagonal blocks per workgroup), leave-one-out pulls and the
+    eigen route; every result bit-identical to the same call done alone (tools/mixed_concurrent_stress.py)."""
+    for k in ('CGP_NO_DAG', 'CGP_DAG_GRID', 'CGP_NO_GRAPH', 'CGP_DAG_TIMEOUT_MS', 'CGP_PIPE_CHUNK'):
+        monkeypatch.delenv(k, raising=False)
+    names, count, bad, errors = _tool('mixed_concurrent_stress').run_mixed(5.)
+    assert not errors and not any(bad) and min(count) >= 2, (names, count, bad, errors)
